@@ -1,0 +1,81 @@
+// Shared declarations for the FG-DM HIP engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FGDM_OK 0
+#define FGDM_ERR_ARG -1
+#define FGDM_ERR_HIP -2
+#define FGDM_ERR_STATE -3
+#define FGDM_ERR_NOMEM -4
+
+// ---------------------------------------------------------------- implicit GEMM
+// out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),  m = (b, oy, ox) output pixel, k = (tap, cin)
+enum IgemmMode { IG_LINEAR = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP2 = 3 };
+enum IgemmAct { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3 };
+enum IgemmOut { OUT_F16 = 0, OUT_F32 = 1, OUT_F32_NCHW = 2, OUT_F16_T = 3 };
+
+struct IgemmArgs {
+    const half_t* A0;      // NHWC fp16 source 0 [B, H, W, C0]  (LINEAR: [M, C0])
+    const half_t* A1;      // optional source 1 (virtual channel concat) [B, H, W, C1]
+    const half_t* Wt;      // packed weights [Npad][K], K = taps * (C0 + C1), k = tap * Ctot + c
+    const float* bias;     // [N] (packed order) or null
+    const float* rowvec;   // per-sample vector added before the activation: rowvec[b * rv_stride + n], or null
+    const half_t* resid;   // [M, ld_res] fp16 added after scale, or null (may alias out)
+    void* out;
+    const half_t* zero;    // >= 256 B of zeros (source for padded / out-of-range rows)
+    int C0, C1;
+    int B, H, W;           // input spatial dims (UP2: dims before the nearest-2x upsample)
+    int Ho, Wo;            // output spatial dims
+    int M, N;              // M = B*Ho*Wo ; N = number of valid packed output columns (GEGLU: 2 * N_out)
+    int K;                 // taps * (C0 + C1)
+    int mode, act, out_kind;
+    int ld_out, ld_res;    // row strides (elements) of out / resid
+    int rv_stride;
+    int rows_per_sample;   // Ho*Wo (LINEAR: tokens per sample) -> sample index b = m / rows_per_sample
+    float scale;           // (acc + bias + rowvec -> act) * scale + resid
+};
+
+int igemm_launch(const IgemmArgs& a, hipStream_t s);
+size_t igemm_npad(int n);   // rows the packed weight must provide
+
+// ---------------------------------------------------------------- norms
+// GroupNorm(32 groups) over NHWC fp16, optionally over the virtual concat of two sources; fp32 statistics.
+int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, int HW,
+                     const float* gamma, const float* beta, float eps, int silu,
+                     half_t* out, float* ws /* >= B*32*2*(chunks+1) floats */, hipStream_t s);
+size_t groupnorm_ws_floats(int B, int HW);
+int layernorm_launch(const half_t* x, int rows, int C, const float* gamma, const float* beta, float eps,
+                     half_t* out, hipStream_t s);
+
+// ---------------------------------------------------------------- attention
+// O[b, t, h*d + :] = softmax(Q K^T * d^-1/2) V ; Q [B, T, ldq], K [B, Tk, ldk], Vt [B, H*d, ldvt] (keys contiguous)
+int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* Vt, int ldvt,
+                     half_t* O, int ldo, int B, int H, int T, int Tk, int d, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise
+int nchw_f32_to_nhwc_f16(const float* x, half_t* y, int B, int C, int HW, int Cpad, hipStream_t s);
+int f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s);
+int im2col3x3(const half_t* x, half_t* A, int B, int H, int W, int C, int stride, int Kpad, hipStream_t s);
+int avgpool2(const half_t* x, half_t* y, int B, int H, int W, int C, hipStream_t s);
+int add_f16(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s);
+int timestep_embed(const int64_t* t, half_t* y, int B, int dim, int rows_pad, hipStream_t s);
+int transpose_pad_keys(const half_t* v, half_t* vt, int B, int Tk, int C, int Tkpad, hipStream_t s);
+// x_prev, pred_x0 from eps (with CFG combine when e_uncond != null); all fp32 NCHW
+int ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,
+              float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, const float* noise,
+              float* x_prev, float* pred_x0, float* e_out, size_t n, hipStream_t s);
+int plms_combine(const float* e_t, const float* e1, const float* e2, const float* e3, int order,
+                 float* e_prime, size_t n, hipStream_t s);
+int axpby(const float* a, float ca, const float* b, float cb, float* y, size_t n, hipStream_t s);
+int ancestral_step(const float* x, const float* eps, float sqrt_recip, float sqrt_recipm1, float coef1, float coef2,
+                   float std, const float* noise, float* out, size_t n, hipStream_t s);
+
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return FGDM_ERR_HIP; } while (0)

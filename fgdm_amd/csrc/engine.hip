@@ -1,0 +1,1179 @@
+// FG-DM sampling engine: model graph (SD-v1.x UNet + FG-DM adapter + ControlNet twin encoders), weight
+// repacking into kernel layouts, activation workspace, and the forward passes, all as launches of the
+// hand-written gfx950 kernels in this directory.  No torch, no BLAS: only the HIP runtime.
+//
+// Reference structure being reproduced (file:line in the reference checkout):
+//   UNetModel.__init__/forward      ldm/modules/diffusionmodules/openaimodel.py:469-734, 808-884 (753-806 original)
+//   ResBlock._forward               openaimodel.py:275-301
+//   SpatialTransformer & friends    ldm/modules/attention.py:152-292
+//   Adapter                         ldm/modules/encoders/adapter.py:280-346
+//   ControlNet / ControlledUnet     controlnet/cldm/cldm.py:27-50, 545-813, 836-849
+#include "common.h"
+#include "../../include/fgdm.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ arena
+// First-fit free-list allocator over hipMalloc'ed slabs.  The allocation sequence of a forward pass is
+// deterministic, so buffers land at the same addresses every call (graph-capture friendly) and recently
+// freed (cache-hot) blocks are reused first.
+struct Arena {
+    struct Blk { char* p; size_t sz; bool free; };
+    std::vector<std::vector<Blk>> slabs;
+    std::vector<char*> bases;
+    size_t slab_bytes = (size_t)4 << 30;
+    size_t in_use = 0, peak = 0;
+
+    ~Arena() { for (char* b : bases) (void)hipFree(b); }
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        for (auto& s : slabs)
+            for (size_t i = 0; i < s.size(); ++i)
+                if (s[i].free && s[i].sz >= bytes) {
+                    if (s[i].sz > bytes) {
+                        Blk rest{s[i].p + bytes, s[i].sz - bytes, true};
+                        s[i].sz = bytes;
+                        s.insert(s.begin() + i + 1, rest);
+                    }
+                    s[i].free = false;
+                    in_use += bytes;
+                    peak = std::max(peak, in_use);
+                    return s[i].p;
+                }
+        const size_t sz = std::max(slab_bytes, bytes);
+        char* base = nullptr;
+        if (hipMalloc(&base, sz) != hipSuccess) return nullptr;
+        bases.push_back(base);
+        slabs.push_back({Blk{base, sz, true}});
+        return alloc(bytes);
+    }
+    void release(void* p) {
+        if (!p) return;
+        for (auto& s : slabs)
+            for (size_t i = 0; i < s.size(); ++i)
+                if (s[i].p == p && !s[i].free) {
+                    s[i].free = true;
+                    in_use -= s[i].sz;
+                    if (i + 1 < s.size() && s[i + 1].free) { s[i].sz += s[i + 1].sz; s.erase(s.begin() + i + 1); }
+                    if (i > 0 && s[i - 1].free) { s[i - 1].sz += s[i].sz; s.erase(s.begin() + i); }
+                    return;
+                }
+    }
+};
+
+struct Tensor {
+    half_t* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t numel() const { return (size_t)B * H * W * C; }
+    int rows() const { return B * H * W; }
+};
+
+struct ParamSlot {
+    std::vector<int64_t> shape;
+    std::vector<float> host;
+    bool loaded = false;
+    size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
+};
+
+struct GemmW {              // packed [npad][K] fp16 weight + fp32 bias (packed column order)
+    half_t* w = nullptr;
+    float* bias = nullptr;
+    int N = 0, K = 0;
+    bool im2col = false;    // conv3x3 whose Cin is not a multiple of 64: K = roundup64(9 * cin_pad)
+    int cin_pad = 0;
+};
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+
+enum LType { L_CONV, L_RES, L_ATTN, L_DOWN, L_UP };
+struct Layer {
+    LType type = L_CONV;
+    int cin = 0, cout = 0, heads = 0;
+    std::string pre;
+    GemmW conv;                                            // L_CONV / L_DOWN / L_UP
+    NormW gn1, gn2; GemmW c1, c2, skip; int emb_off = 0;   // L_RES
+    NormW gn, ln1, ln2, ln3;                               // L_ATTN
+    GemmW pin, pout, qk1, v1, o1, q2, k2, v2, o2, ffp, ffo;
+};
+typedef std::vector<Layer> Block;
+
+struct AdapterBlk { int ic = 0, oc = 0; bool down = false; std::string pre; GemmW in_conv, b1, b2; };
+
+struct Net {
+    std::string prefix;
+    bool control = false;
+    GemmW time0, time2, emb_all;
+    int emb_total = 0;
+    std::vector<Block> input, output;
+    Block middle;
+    NormW out_gn; GemmW out_conv;                          // UNet only
+    bool has_adapter = false;                              // UNet only
+    GemmW ad_conv_in; std::vector<AdapterBlk> ad_body;
+    std::vector<GemmW> zero_convs; GemmW mid_out;          // ControlNet only
+    std::vector<int> zero_ch;
+    GemmW hint_convs[8];
+    Tensor guided;                                         // cached input_hint_block output (persistent hipMalloc)
+};
+
+static int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct fgdm_engine {
+    fgdm_config cfg{};
+    int device = -1;
+    bool device_ready = false, finalized = false;
+    std::string err;
+    std::vector<std::string> order;
+    std::unordered_map<std::string, ParamSlot> params;
+    Net unet;
+    std::vector<Net> cns;
+    Arena arena;
+    half_t* zero = nullptr;
+    std::vector<void*> weight_allocs;
+    hipStream_t s = nullptr;      // stream of the call in flight
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+
+    // ------------------------------------------------------------------------------------ graph + registry
+    void reg(const std::string& name, std::vector<int64_t> shape) {
+        order.push_back(name);
+        params[name].shape = std::move(shape);
+    }
+    void reg_wb(const std::string& pre, std::vector<int64_t> wshape) {
+        const int64_t n = wshape[0];
+        reg(pre + ".weight", std::move(wshape));
+        reg(pre + ".bias", {n});
+    }
+    void reg_res(const std::string& p, int cin, int cout, int temb) {
+        reg_wb(p + "in_layers.0", {cin});
+        reg_wb(p + "in_layers.2", {cout, cin, 3, 3});
+        reg_wb(p + "emb_layers.1", {cout, temb});
+        reg_wb(p + "out_layers.0", {cout});
+        reg_wb(p + "out_layers.3", {cout, cout, 3, 3});
+        if (cin != cout) reg_wb(p + "skip_connection", {cout, cin, 1, 1});
+    }
+    void reg_attn(const std::string& p, int ch, int ctx) {
+        reg_wb(p + "norm", {ch});
+        reg_wb(p + "proj_in", {ch, ch, 1, 1});
+        const std::string t = p + "transformer_blocks.0.";
+        reg(t + "attn1.to_q.weight", {ch, ch});
+        reg(t + "attn1.to_k.weight", {ch, ch});
+        reg(t + "attn1.to_v.weight", {ch, ch});
+        reg_wb(t + "attn1.to_out.0", {ch, ch});
+        reg_wb(t + "ff.net.0.proj", {8 * ch, ch});
+        reg_wb(t + "ff.net.2", {ch, 4 * ch});
+        reg(t + "attn2.to_q.weight", {ch, ch});
+        reg(t + "attn2.to_k.weight", {ch, ctx});
+        reg(t + "attn2.to_v.weight", {ch, ctx});
+        reg_wb(t + "attn2.to_out.0", {ch, ch});
+        reg_wb(t + "norm1", {ch});
+        reg_wb(t + "norm2", {ch});
+        reg_wb(t + "norm3", {ch});
+        reg_wb(p + "proj_out", {ch, ch, 1, 1});
+    }
+    void reg_block(const std::string& pre, Block& blk, int temb, int ctx) {
+        for (size_t j = 0; j < blk.size(); ++j) {
+            Layer& l = blk[j];
+            l.pre = pre + std::to_string(j) + ".";
+            switch (l.type) {
+                case L_CONV: reg_wb(l.pre.substr(0, l.pre.size() - 1), {l.cout, l.cin, 3, 3}); break;
+                case L_RES: reg_res(l.pre, l.cin, l.cout, temb); break;
+                case L_ATTN: reg_attn(l.pre, l.cin, ctx); break;
+                case L_DOWN: reg_wb(l.pre + "op", {l.cin, l.cin, 3, 3}); break;
+                case L_UP: reg_wb(l.pre + "conv", {l.cin, l.cin, 3, 3}); break;
+            }
+        }
+    }
+    static Layer mk(LType t, int cin, int cout, int heads = 0) {
+        Layer l; l.type = t; l.cin = cin; l.cout = cout; l.heads = heads; return l;
+    }
+    bool in_ares(int ds) const {
+        for (int i = 0; i < cfg.n_attention_resolutions; ++i) if (cfg.attention_resolutions[i] == ds) return true;
+        return false;
+    }
+    // openaimodel.py:558-718 / cldm.py:640-787
+    void build_net(Net& n, const std::string& prefix, bool control, bool adapter) {
+        n.prefix = prefix; n.control = control; n.has_adapter = adapter;
+        const int mc = cfg.model_channels, temb = 4 * mc, ctx = cfg.context_dim, heads = cfg.num_heads;
+        reg_wb(prefix + "time_embed.0", {temb, mc});
+        reg_wb(prefix + "time_embed.2", {temb, temb});
+        if (adapter) {   // registration order of the reference: adapter precedes input_blocks (openaimodel.py:551-558)
+            static const int chs[4] = {320, 640, 1280, 1280};
+            const std::string ap = prefix + "adapter.";
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    AdapterBlk b;
+                    b.down = (i != 0 && j == 0);
+                    b.ic = b.down ? chs[i - 1] : chs[i];
+                    b.oc = chs[i];
+                    b.pre = ap + "body." + std::to_string(i * 2 + j) + ".";
+                    if (b.ic != b.oc) reg_wb(b.pre + "in_conv", {b.oc, b.ic, 1, 1});
+                    reg_wb(b.pre + "block1", {b.oc, b.oc, 3, 3});
+                    reg_wb(b.pre + "block2", {b.oc, b.oc, 1, 1});
+                    n.ad_body.push_back(b);
+                }
+            reg_wb(ap + "conv_in", {chs[0], cfg.in_channels, 3, 3});
+        }
+        std::vector<int> chans;
+        int ch = mc, ds = 1;
+        n.input.push_back({mk(L_CONV, cfg.in_channels, mc)});
+        chans.push_back(mc);
+        for (int level = 0; level < cfg.n_levels; ++level) {
+            const int mult = cfg.channel_mult[level];
+            for (int r = 0; r < cfg.num_res_blocks; ++r) {
+                Block b{mk(L_RES, ch, mult * mc)};
+                ch = mult * mc;
+                if (in_ares(ds)) b.push_back(mk(L_ATTN, ch, ch, heads));
+                n.input.push_back(b);
+                chans.push_back(ch);
+            }
+            if (level != cfg.n_levels - 1) {
+                n.input.push_back({mk(L_DOWN, ch, ch)});
+                chans.push_back(ch);
+                ds *= 2;
+            }
+        }
+        n.middle = {mk(L_RES, ch, ch), mk(L_ATTN, ch, ch, heads), mk(L_RES, ch, ch)};
+        for (size_t i = 0; i < n.input.size(); ++i) reg_block(prefix + "input_blocks." + std::to_string(i) + ".", n.input[i], temb, ctx);
+        if (control) {
+            for (size_t i = 0; i < n.input.size(); ++i) {
+                const int zc = n.input[i].back().type == L_DOWN ? n.input[i].back().cin : n.input[i][0].cout;
+                n.zero_ch.push_back(zc);
+                reg_wb(prefix + "zero_convs." + std::to_string(i) + ".0", {zc, zc, 1, 1});
+            }
+            static const int hc[7] = {16, 16, 32, 32, 96, 96, 256};
+            int prev = cfg.hint_channels;
+            for (int k = 0; k < 8; ++k) {
+                const int oc = k < 7 ? hc[k] : mc;
+                reg_wb(prefix + "input_hint_block." + std::to_string(2 * k), {oc, prev, 3, 3});
+                prev = oc;
+            }
+            reg_block(prefix + "middle_block.", n.middle, temb, ctx);
+            reg_wb(prefix + "middle_block_out.0", {ch, ch, 1, 1});
+            return;
+        }
+        reg_block(prefix + "middle_block.", n.middle, temb, ctx);
+        for (int level = cfg.n_levels - 1; level >= 0; --level) {
+            const int mult = cfg.channel_mult[level];
+            for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+                const int ich = chans.back();
+                chans.pop_back();
+                Block b{mk(L_RES, ch + ich, mc * mult)};
+                ch = mc * mult;
+                if (in_ares(ds)) b.push_back(mk(L_ATTN, ch, ch, heads));
+                if (level && i == cfg.num_res_blocks) { b.push_back(mk(L_UP, ch, ch)); ds /= 2; }
+                n.output.push_back(b);
+            }
+        }
+        for (size_t i = 0; i < n.output.size(); ++i) reg_block(prefix + "output_blocks." + std::to_string(i) + ".", n.output[i], temb, ctx);
+        reg_wb(prefix + "out.0", {mc});
+        reg_wb(prefix + "out.2", {cfg.out_channels, mc, 3, 3});
+    }
+    int build() {
+        if (cfg.n_levels < 1 || cfg.n_levels > FGDM_MAX_LEVELS || cfg.model_channels <= 0 || (cfg.model_channels & 63) ||
+            cfg.num_heads <= 0 || cfg.n_controlnets < 0 || cfg.n_controlnets > FGDM_MAX_CONTROLNETS ||
+            (cfg.context_dim & 63) || cfg.in_channels != 4)
+            return fail(FGDM_ERR_ARG, "unsupported config (model_channels and context_dim must be multiples of 64, in_channels 4)");
+        for (int l = 0; l < cfg.n_levels; ++l) {
+            const int ch = cfg.model_channels * cfg.channel_mult[l];
+            if (ch % cfg.num_heads) return fail(FGDM_ERR_ARG, "channels not divisible by heads");
+        }
+        if (cfg.use_adapter && !(cfg.model_channels == 320 && cfg.n_levels == 4 && cfg.num_res_blocks == 2))
+            return fail(FGDM_ERR_ARG, "FG-DM adapter requires the SD-v1 topology (openaimodel.py:554-556,855-859)");
+        build_net(unet, "model.diffusion_model.", false, cfg.use_adapter != 0);
+        cns.resize(cfg.n_controlnets);
+        for (int k = 0; k < cfg.n_controlnets; ++k)
+            build_net(cns[k], k == 0 ? std::string("control_model.") : "control_model_" + std::to_string(k) + ".", true, false);
+        return FGDM_OK;
+    }
+
+    // ------------------------------------------------------------------------------------ weight packing
+    const ParamSlot* slot(const std::string& name) {
+        auto it = params.find(name);
+        if (it == params.end() || !it->second.loaded) { err = "parameter not loaded: " + name; return nullptr; }
+        return &it->second;
+    }
+    template <typename T> T* upload(const std::vector<T>& h) {
+        T* d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(h.size() * sizeof(T), 256)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        weight_allocs.push_back(d);
+        return d;
+    }
+    // rows: list of (source float*, n_rows) stacked along N; each source is [n][K_src] row-major;
+    // kmap(k_packed) -> k_src or -1.  row_perm maps packed row -> stacked source row (GEGLU interleave).
+    int pack_rows(GemmW& g, const std::vector<std::pair<const float*, int>>& srcs, int K_src, int K,
+                  const std::vector<int>& kmap, const std::vector<const float*>& biases, bool geglu) {
+        int N = 0;
+        for (auto& s : srcs) N += s.second;
+        const size_t npad = igemm_npad(N);
+        std::vector<half_t> w(npad * (size_t)K, (half_t)0);
+        std::vector<float> bias(npad, 0.f);
+        std::vector<const float*> rowp(N);
+        std::vector<float> bflat(N, 0.f);
+        int r = 0;
+        for (size_t si = 0; si < srcs.size(); ++si)
+            for (int i = 0; i < srcs[si].second; ++i, ++r) {
+                rowp[r] = srcs[si].first + (size_t)i * K_src;
+                if (si < biases.size() && biases[si]) bflat[r] = biases[si][i];
+            }
+        for (int pr = 0; pr < N; ++pr) {
+            int sr = pr;
+            if (geglu) {   // packed 64-row groups = [32 value rows | 32 gate rows]; gate rows live at N/2 + i
+                const int grp = pr >> 6, within = pr & 63;
+                sr = within < 32 ? grp * 32 + within : N / 2 + grp * 32 + (within - 32);
+            }
+            const float* src = rowp[sr];
+            half_t* dst = w.data() + (size_t)pr * K;
+            if (kmap.empty()) for (int k = 0; k < K; ++k) dst[k] = (half_t)src[k];
+            else for (int k = 0; k < K; ++k) if (kmap[k] >= 0) dst[k] = (half_t)src[kmap[k]];
+            bias[pr] = bflat[sr];
+        }
+        g.N = N; g.K = K;
+        g.w = upload(w);
+        g.bias = upload(bias);
+        return (g.w && g.bias) ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed while packing weights");
+    }
+    int pack_linear(GemmW& g, const std::string& pre, bool has_bias, bool geglu = false) {
+        const ParamSlot* w = slot(pre + ".weight");
+        if (!w) return FGDM_ERR_STATE;
+        const ParamSlot* b = has_bias ? slot(pre + ".bias") : nullptr;
+        if (has_bias && !b) return FGDM_ERR_STATE;
+        const int N = (int)w->shape[0], K = (int)(w->numel() / w->shape[0]);
+        if (K & 63) return fail(FGDM_ERR_ARG, "linear K not a multiple of 64: " + pre);
+        return pack_rows(g, {{w->host.data(), N}}, K, K, {}, {b ? b->host.data() : nullptr}, geglu);
+    }
+    int pack_stack(GemmW& g, const std::vector<std::string>& pres, bool has_bias) {
+        std::vector<std::pair<const float*, int>> srcs;
+        std::vector<const float*> biases;
+        int K = 0;
+        for (auto& pre : pres) {
+            const ParamSlot* w = slot(pre + ".weight");
+            if (!w) return FGDM_ERR_STATE;
+            K = (int)(w->numel() / w->shape[0]);
+            srcs.push_back({w->host.data(), (int)w->shape[0]});
+            if (has_bias) { const ParamSlot* b = slot(pre + ".bias"); if (!b) return FGDM_ERR_STATE; biases.push_back(b->host.data()); }
+        }
+        return pack_rows(g, srcs, K, K, {}, biases, false);
+    }
+    // conv3x3 [Cout, Cin, 3, 3] -> k = tap * Cin + c (implicit GEMM) or im2col layout with padded Cin / K
+    int pack_conv3(GemmW& g, const std::string& pre) {
+        const ParamSlot* w = slot(pre + ".weight");
+        const ParamSlot* b = slot(pre + ".bias");
+        if (!w || !b) return FGDM_ERR_STATE;
+        const int N = (int)w->shape[0], Cin = (int)w->shape[1];
+        const bool implicit = (Cin % 64) == 0;
+        const int cp = implicit ? Cin : roundup(Cin, Cin % 8 == 0 ? 8 : 4);
+        const int K = implicit ? 9 * Cin : roundup(9 * cp, 64);
+        std::vector<int> kmap(K, -1);
+        for (int tap = 0; tap < 9; ++tap)
+            for (int c = 0; c < Cin; ++c) kmap[tap * cp + c] = c * 9 + tap;   // source index within a row: [Cin][3][3]
+        g.im2col = !implicit;
+        g.cin_pad = cp;
+        return pack_rows(g, {{w->host.data(), N}}, Cin * 9, K, kmap, {b->host.data()}, false);
+    }
+    int pack_norm(NormW& n, const std::string& pre) {
+        const ParamSlot* w = slot(pre + ".weight");
+        const ParamSlot* b = slot(pre + ".bias");
+        if (!w || !b) return FGDM_ERR_STATE;
+        n.C = (int)w->shape[0];
+        n.g = upload(w->host);
+        n.b = upload(b->host);
+        return (n.g && n.b) ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed");
+    }
+#define CHK(x) do { int _rc = (x); if (_rc != FGDM_OK) return _rc; } while (0)
+    int pack_block(Block& blk) {
+        for (Layer& l : blk) {
+            const std::string& p = l.pre;
+            switch (l.type) {
+                case L_CONV: CHK(pack_conv3(l.conv, p.substr(0, p.size() - 1))); break;
+                case L_DOWN: CHK(pack_conv3(l.conv, p + "op")); break;
+                case L_UP: CHK(pack_conv3(l.conv, p + "conv")); break;
+                case L_RES:
+                    CHK(pack_norm(l.gn1, p + "in_layers.0"));
+                    CHK(pack_conv3(l.c1, p + "in_layers.2"));
+                    CHK(pack_norm(l.gn2, p + "out_layers.0"));
+                    CHK(pack_conv3(l.c2, p + "out_layers.3"));
+                    if (l.cin != l.cout) CHK(pack_linear(l.skip, p + "skip_connection", true));
+                    break;
+                case L_ATTN: {
+                    const std::string t = p + "transformer_blocks.0.";
+                    CHK(pack_norm(l.gn, p + "norm"));
+                    CHK(pack_linear(l.pin, p + "proj_in", true));
+                    CHK(pack_linear(l.pout, p + "proj_out", true));
+                    CHK(pack_norm(l.ln1, t + "norm1"));
+                    CHK(pack_norm(l.ln2, t + "norm2"));
+                    CHK(pack_norm(l.ln3, t + "norm3"));
+                    CHK(pack_stack(l.qk1, {t + "attn1.to_q", t + "attn1.to_k"}, false));
+                    CHK(pack_linear(l.v1, t + "attn1.to_v", false));
+                    CHK(pack_linear(l.o1, t + "attn1.to_out.0", true));
+                    CHK(pack_linear(l.q2, t + "attn2.to_q", false));
+                    CHK(pack_linear(l.k2, t + "attn2.to_k", false));
+                    CHK(pack_linear(l.v2, t + "attn2.to_v", false));
+                    CHK(pack_linear(l.o2, t + "attn2.to_out.0", true));
+                    CHK(pack_linear(l.ffp, t + "ff.net.0.proj", true, true));
+                    CHK(pack_linear(l.ffo, t + "ff.net.2", true));
+                    break;
+                }
+            }
+        }
+        return FGDM_OK;
+    }
+    int pack_net(Net& n) {
+        CHK(pack_linear(n.time0, n.prefix + "time_embed.0", true));
+        CHK(pack_linear(n.time2, n.prefix + "time_embed.2", true));
+        // every ResBlock's emb_layers Linear stacked into one GEMM per evaluation (openaimodel.py:238-244, 290)
+        std::vector<std::string> embs;
+        int off = 0;
+        auto collect = [&](Block& b) {
+            for (Layer& l : b) if (l.type == L_RES) { l.emb_off = off; off += l.cout; embs.push_back(l.pre + "emb_layers.1"); }
+        };
+        for (auto& b : n.input) collect(b);
+        collect(n.middle);
+        for (auto& b : n.output) collect(b);
+        n.emb_total = off;
+        CHK(pack_stack(n.emb_all, embs, true));
+        for (auto& b : n.input) CHK(pack_block(b));
+        CHK(pack_block(n.middle));
+        for (auto& b : n.output) CHK(pack_block(b));
+        if (!n.control) {
+            CHK(pack_norm(n.out_gn, n.prefix + "out.0"));
+            CHK(pack_conv3(n.out_conv, n.prefix + "out.2"));
+            if (n.has_adapter) {
+                CHK(pack_conv3(n.ad_conv_in, n.prefix + "adapter.conv_in"));
+                for (auto& b : n.ad_body) {
+                    if (b.ic != b.oc) CHK(pack_linear(b.in_conv, b.pre + "in_conv", true));
+                    CHK(pack_conv3(b.b1, b.pre + "block1"));
+                    CHK(pack_linear(b.b2, b.pre + "block2", true));
+                }
+            }
+        } else {
+            n.zero_convs.resize(n.input.size());
+            for (size_t i = 0; i < n.input.size(); ++i)
+                CHK(pack_linear(n.zero_convs[i], n.prefix + "zero_convs." + std::to_string(i) + ".0", true));
+            CHK(pack_linear(n.mid_out, n.prefix + "middle_block_out.0", true));
+            for (int k = 0; k < 8; ++k) CHK(pack_conv3(n.hint_convs[k], n.prefix + "input_hint_block." + std::to_string(2 * k)));
+        }
+        // staging for this net is no longer needed
+        for (auto& name : order)
+            if (name.compare(0, n.prefix.size(), n.prefix) == 0) { auto& ps = params[name]; std::vector<float>().swap(ps.host); }
+        return FGDM_OK;
+    }
+
+    // ------------------------------------------------------------------------------------ runtime helpers
+    Tensor talloc(int B, int H, int W, int C) {
+        Tensor t; t.B = B; t.H = H; t.W = W; t.C = C;
+        t.p = (half_t*)arena.alloc(t.numel() * sizeof(half_t));
+        return t;
+    }
+    void tfree(Tensor& t) { arena.release(t.p); t.p = nullptr; }
+
+    struct Epi {
+        int act = ACT_NONE;
+        const float* rowvec = nullptr; int rv_stride = 0;
+        const half_t* resid = nullptr; int ld_res = 0;
+        float scale = 1.f;
+        int out_kind = OUT_F16;
+        void* out = nullptr;   // override destination (OUT_F32* kinds or in-place adds)
+        int ld_out = 0;
+        int rps = 0;           // rows per sample override
+    };
+    // out = epilogue(A W^T): LINEAR over rows of x0 (x1 = virtual concat), or conv3x3 in `mode`
+    int gemm(const GemmW& w, int mode, const Tensor& x0, const Tensor* x1, int Ho, int Wo, const Epi& e, Tensor* out) {
+        IgemmArgs a{};
+        a.A0 = x0.p; a.C0 = x0.C;
+        a.A1 = x1 ? x1->p : nullptr; a.C1 = x1 ? x1->C : 0;
+        a.Wt = w.w; a.bias = w.bias;
+        a.rowvec = e.rowvec; a.rv_stride = e.rv_stride;
+        a.resid = e.resid; a.ld_res = e.ld_res;
+        a.zero = zero;
+        a.B = x0.B; a.H = x0.H; a.W = x0.W; a.Ho = Ho; a.Wo = Wo;
+        a.M = x0.B * Ho * Wo;
+        a.N = w.N;
+        a.K = w.K;
+        a.mode = mode; a.act = e.act; a.out_kind = e.out_kind;
+        const int nout = e.act == ACT_GEGLU ? w.N / 2 : w.N;
+        a.out = e.out ? e.out : (void*)out->p;
+        a.ld_out = e.ld_out ? e.ld_out : nout;
+        a.rows_per_sample = e.rps ? e.rps : Ho * Wo;
+        a.scale = e.scale;
+        const int taps = mode == IG_LINEAR ? 1 : 9;
+        if (taps * (a.C0 + a.C1) != a.K) return fail(FGDM_ERR_ARG, "gemm: K mismatch");
+        if (!a.out) return fail(FGDM_ERR_NOMEM, "gemm: null output (workspace exhausted?)");
+        const int rc = igemm_launch(a, s);
+        return rc == FGDM_OK ? rc : fail(rc, "igemm launch failed");
+    }
+    // conv3x3 (stride 1/2, or on the nearest-2x upsampled input) -> new tensor
+    int conv3(const GemmW& w, const Tensor& x, const Tensor* x1, int stride, bool up, Epi e, Tensor* out) {
+        int Ho = x.H, Wo = x.W, mode = IG_CONV3;
+        if (up) { Ho *= 2; Wo *= 2; mode = IG_CONV3_UP2; }
+        else if (stride == 2) { Ho = (x.H - 1) / 2 + 1; Wo = (x.W - 1) / 2 + 1; mode = IG_CONV3_S2; }
+        const bool own_out = (e.out == nullptr);
+        if (own_out) { *out = talloc(x.B, Ho, Wo, w.N); if (!out->p) return fail(FGDM_ERR_NOMEM, "workspace"); }
+        if (!w.im2col) return gemm(w, mode, x, x1, Ho, Wo, e, out);
+        if (up || x1 || x.C != w.cin_pad) return fail(FGDM_ERR_ARG, "im2col conv path: unsupported combination");
+        Tensor A = talloc(1, 1, x.B * Ho * Wo, w.K);
+        if (!A.p) return fail(FGDM_ERR_NOMEM, "workspace (im2col)");
+        int rc = im2col3x3(x.p, A.p, x.B, x.H, x.W, x.C, stride, w.K, s);
+        if (rc != FGDM_OK) return fail(rc, "im2col failed");
+        Tensor Av = A; Av.B = x.B; Av.H = Ho; Av.W = Wo; Av.C = w.K;
+        if (!e.rps) e.rps = Ho * Wo;
+        rc = gemm(w, IG_LINEAR, Av, nullptr, Ho, Wo, e, out);
+        tfree(A);
+        return rc;
+    }
+    int linear(const GemmW& w, const Tensor& x, Epi e, Tensor* out, const Tensor* x1 = nullptr) {
+        if (!e.out) { *out = talloc(x.B, x.H, x.W, e.act == ACT_GEGLU ? w.N / 2 : w.N); if (!out->p) return fail(FGDM_ERR_NOMEM, "workspace"); }
+        return gemm(w, IG_LINEAR, x, x1, x.H, x.W, e, out);
+    }
+    int gnorm(const NormW& n, const Tensor& x, const Tensor* x1, float eps, bool silu, Tensor* out) {
+        const int C = x.C + (x1 ? x1->C : 0);
+        *out = talloc(x.B, x.H, x.W, C);
+        float* ws = (float*)arena.alloc(groupnorm_ws_floats(x.B, x.H * x.W) * sizeof(float));
+        if (!out->p || !ws) return fail(FGDM_ERR_NOMEM, "workspace");
+        const int rc = groupnorm_launch(x.p, x.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, x.B, x.H * x.W, n.g, n.b, eps,
+                                        silu ? 1 : 0, out->p, ws, s);
+        arena.release(ws);
+        return rc == FGDM_OK ? rc : fail(rc, "groupnorm launch failed");
+    }
+    int lnorm(const NormW& n, const Tensor& x, Tensor* out) {
+        *out = talloc(x.B, x.H, x.W, x.C);
+        if (!out->p) return fail(FGDM_ERR_NOMEM, "workspace");
+        const int rc = layernorm_launch(x.p, x.rows(), x.C, n.g, n.b, 1e-5f, out->p, s);
+        return rc == FGDM_OK ? rc : fail(rc, "layernorm launch failed");
+    }
+
+    // ------------------------------------------------------------------------------------ layers
+    struct EmbCtx { const float* emb_all; int stride; };
+
+    // ResBlock._forward (openaimodel.py:275-301); x1 = skip tensor of the decoder's channel concat
+    int res_fwd(const Layer& l, const Tensor& x, const Tensor* x1, const EmbCtx& ec, Tensor* out) {
+        Tensor g1, h, g2, sk;
+        CHK(gnorm(l.gn1, x, x1, 1e-5f, true, &g1));
+        Epi e1; e1.rowvec = ec.emb_all + l.emb_off; e1.rv_stride = ec.stride;
+        CHK(conv3(l.c1, g1, nullptr, 1, false, e1, &h));
+        tfree(g1);
+        CHK(gnorm(l.gn2, h, nullptr, 1e-5f, true, &g2));
+        tfree(h);
+        Epi e2;
+        if (l.cin != l.cout) {
+            CHK(linear(l.skip, x, Epi{}, &sk, x1));
+            e2.resid = sk.p; e2.ld_res = sk.C;
+        } else {
+            e2.resid = x.p; e2.ld_res = x.C;
+        }
+        CHK(conv3(l.c2, g2, nullptr, 1, false, e2, out));
+        tfree(g2);
+        if (sk.p) tfree(sk);
+        return FGDM_OK;
+    }
+
+    // SpatialTransformer.forward with one BasicTransformerBlock (attention.py:234-292)
+    int attn_fwd(const Layer& l, const Tensor& x, const Tensor& ctx16, Tensor* out) {
+        const int B = x.B, T = x.H * x.W, C = x.C, d = C / l.heads;
+        Tensor g, h, n, qk, vt, a, h2, q2, k2, v2t, f;
+        CHK(gnorm(l.gn, x, nullptr, 1e-6f, false, &g));
+        CHK(linear(l.pin, g, Epi{}, &h));
+        tfree(g);
+        // --- attn1 (self)
+        CHK(lnorm(l.ln1, h, &n));
+        CHK(linear(l.qk1, n, Epi{}, &qk));
+        const int Tp = roundup(T, 64);
+        vt = talloc(B, 1, C, Tp);
+        if (!vt.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (Tp != T) HIP_TRY(hipMemsetAsync(vt.p, 0, vt.numel() * sizeof(half_t), s));
+        { Epi e; e.out_kind = OUT_F16_T; e.out = vt.p; e.ld_out = Tp; e.rps = T; CHK(linear(l.v1, n, e, nullptr)); }
+        tfree(n);
+        a = talloc(B, x.H, x.W, C);
+        if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        { int rc = attention_launch(qk.p, 2 * C, qk.p + C, 2 * C, vt.p, Tp, a.p, C, B, l.heads, T, T, d, s);
+          if (rc != FGDM_OK) return fail(rc, "attention launch failed (unsupported head dim?)"); }
+        tfree(qk); tfree(vt);
+        { Epi e; e.resid = h.p; e.ld_res = C; CHK(linear(l.o1, a, e, &h2)); }
+        tfree(a); tfree(h);
+        // --- attn2 (cross, 77-token context)
+        CHK(lnorm(l.ln2, h2, &n));
+        CHK(linear(l.q2, n, Epi{}, &q2));
+        tfree(n);
+        const int Tk = ctx16.H * ctx16.W, Tkp = roundup(Tk, 64);
+        CHK(linear(l.k2, ctx16, Epi{}, &k2));
+        v2t = talloc(B, 1, C, Tkp);
+        if (!v2t.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (Tkp != Tk) HIP_TRY(hipMemsetAsync(v2t.p, 0, v2t.numel() * sizeof(half_t), s));
+        { Epi e; e.out_kind = OUT_F16_T; e.out = v2t.p; e.ld_out = Tkp; e.rps = Tk; CHK(linear(l.v2, ctx16, e, nullptr)); }
+        a = talloc(B, x.H, x.W, C);
+        if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        { int rc = attention_launch(q2.p, C, k2.p, C, v2t.p, Tkp, a.p, C, B, l.heads, T, Tk, d, s);
+          if (rc != FGDM_OK) return fail(rc, "attention launch failed"); }
+        tfree(q2); tfree(k2); tfree(v2t);
+        { Epi e; e.resid = h2.p; e.ld_res = C; CHK(linear(l.o2, a, e, &h)); }
+        tfree(a); tfree(h2);
+        // --- GEGLU feed-forward
+        CHK(lnorm(l.ln3, h, &n));
+        { Epi e; e.act = ACT_GEGLU; CHK(linear(l.ffp, n, e, &f)); }
+        tfree(n);
+        { Epi e; e.resid = h.p; e.ld_res = C; CHK(linear(l.ffo, f, e, &h2)); }
+        tfree(f); tfree(h);
+        { Epi e; e.resid = x.p; e.ld_res = C; CHK(linear(l.pout, h2, e, out)); }
+        tfree(h2);
+        return FGDM_OK;
+    }
+
+    // TimestepEmbedSequential over one block; x1 = decoder skip (consumed by the block's first ResBlock)
+    int block_fwd(const Block& blk, Tensor x, bool own_x, const Tensor* x1, const EmbCtx& ec, const Tensor& ctx16,
+                  const half_t* conv_resid, Tensor* out) {
+        Tensor cur = x;
+        bool own = own_x;
+        for (size_t j = 0; j < blk.size(); ++j) {
+            const Layer& l = blk[j];
+            Tensor nxt;
+            switch (l.type) {
+                case L_CONV: { Epi e; if (conv_resid) { e.resid = conv_resid; e.ld_res = l.cout; }
+                               CHK(conv3(l.conv, cur, nullptr, 1, false, e, &nxt)); break; }
+                case L_RES: CHK(res_fwd(l, cur, j == 0 ? x1 : nullptr, ec, &nxt)); break;
+                case L_ATTN: CHK(attn_fwd(l, cur, ctx16, &nxt)); break;
+                case L_DOWN: CHK(conv3(l.conv, cur, nullptr, 2, false, Epi{}, &nxt)); break;
+                case L_UP: CHK(conv3(l.conv, cur, nullptr, 1, true, Epi{}, &nxt)); break;
+            }
+            if (own) tfree(cur);
+            cur = nxt;
+            own = true;
+        }
+        *out = cur;
+        return FGDM_OK;
+    }
+
+    // timestep_embedding -> time_embed -> SiLU -> all emb_layers (util.py:160-180; openaimodel.py:537-542,827-828,290)
+    int embed(Net& n, const int64_t* t, int B, float** emb_all) {
+        const int mc = cfg.model_channels;
+        Tensor te = talloc(1, 1, B, mc), e1, e2;
+        if (!te.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (timestep_embed(t, te.p, B, mc, B, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "timestep_embed");
+        { Epi e; e.act = ACT_SILU; e.rps = 1; CHK(linear(n.time0, te, e, &e1)); }
+        { Epi e; e.act = ACT_SILU; e.rps = 1; CHK(linear(n.time2, e1, e, &e2)); }   // = SiLU(emb): the only use of emb
+        *emb_all = (float*)arena.alloc((size_t)B * n.emb_total * sizeof(float));
+        if (!*emb_all) return fail(FGDM_ERR_NOMEM, "workspace");
+        { Epi e; e.out_kind = OUT_F32; e.out = *emb_all; e.ld_out = n.emb_total; e.rps = 1; CHK(linear(n.emb_all, e2, e, nullptr)); }
+        tfree(te); tfree(e1); tfree(e2);
+        return FGDM_OK;
+    }
+
+    // Adapter.forward (adapter.py:334-346): four feature maps from the (noisy) latent itself.
+    // ResnetBlock (adapter.py:301-313, ksize=1, sk=True): [AvgPool2d(2)] -> [conv1x1] -> conv3x3 -> ReLU -> conv1x1 -> +x
+    int adapter_fwd(Net& n, const Tensor& x4, Tensor feats[4]) {
+        Tensor cur;
+        CHK(conv3(n.ad_conv_in, x4, nullptr, 1, false, Epi{}, &cur));
+        auto drop = [&](Tensor& t) {   // free a temporary unless it is one of the returned features
+            for (int f = 0; f < 4; ++f) if (feats[f].p == t.p) return;
+            tfree(t);
+        };
+        for (size_t k = 0; k < n.ad_body.size(); ++k) {
+            const AdapterBlk& b = n.ad_body[k];
+            if (b.down) {
+                Tensor p = talloc(cur.B, cur.H / 2, cur.W / 2, cur.C);
+                if (!p.p) return fail(FGDM_ERR_NOMEM, "workspace");
+                if (avgpool2(cur.p, p.p, cur.B, cur.H, cur.W, cur.C, s) != FGDM_OK)
+                    return fail(FGDM_ERR_ARG, "avgpool2: latent size must be divisible by 8 for the adapter");
+                drop(cur);
+                cur = p;
+            }
+            if (b.ic != b.oc) { Tensor y; CHK(linear(b.in_conv, cur, Epi{}, &y)); drop(cur); cur = y; }
+            Tensor h, y;
+            { Epi e; e.act = ACT_RELU; CHK(conv3(b.b1, cur, nullptr, 1, false, e, &h)); }
+            { Epi e; e.resid = cur.p; e.ld_res = cur.C; CHK(linear(b.b2, h, e, &y)); }
+            tfree(h);
+            drop(cur);
+            cur = y;
+            if (k % 2 == 1) feats[k / 2] = cur;   // nums_rb = 2: a feature after every second block
+        }
+        return FGDM_OK;
+    }
+
+    int ensure_device() {
+        if (device_ready) return FGDM_OK;
+        if (hipSetDevice(device) != hipSuccess) return fail(FGDM_ERR_HIP, "hipSetDevice failed (no GPU?)");
+        if (hipMalloc(&zero, 4096) != hipSuccess || hipMemset(zero, 0, 4096) != hipSuccess) return fail(FGDM_ERR_HIP, "hipMalloc failed");
+        if (cfg.workspace_bytes > 0) arena.slab_bytes = (size_t)cfg.workspace_bytes;
+        device_ready = true;
+        return FGDM_OK;
+    }
+
+    // ControlNet.forward (cldm.py:792-813).  fused = true: every zero-conv output is scaled and ADDED in place into
+    // the UNet's skip tensor hs[i] / h_mid (cldm.py:40,46 + :846), so control residuals never hit HBM separately.
+    // fused = false: raw residuals are written as fp32 NCHW into out32 (test entry).
+    int controlnet_fwd(Net& n, const Tensor& x4, const int64_t* t, const Tensor& ctx16, const float* scales,
+                       std::vector<Tensor>* hs, Tensor* h_mid, bool only_mid, float* out32, int64_t out_cap) {
+        const int B = x4.B;
+        if (!n.guided.p) return fail(FGDM_ERR_STATE, "fgdm_set_hint has not been called for this ControlNet");
+        if (!(n.guided.B == B || 2 * n.guided.B == B) || n.guided.H != x4.H || n.guided.W != x4.W)
+            return fail(FGDM_ERR_ARG, "cached hint does not match the batch / latent size");
+        float* emb = nullptr;
+        CHK(embed(n, t, B, &emb));
+        EmbCtx ec{emb, n.emb_total};
+        Tensor h;
+        int64_t off = 0;
+        auto zero_conv = [&](const GemmW& zw, const Tensor& src, int idx) -> int {
+            Epi e;
+            if (out32) {
+                const int64_t cnt = (int64_t)src.numel();
+                if (off + cnt > out_cap) return fail(FGDM_ERR_ARG, "fgdm_controlnet: output buffer too small");
+                e.out_kind = OUT_F32_NCHW; e.out = out32 + off; e.ld_out = src.H * src.W;
+                off += cnt;
+                return linear(zw, src, e, nullptr);
+            }
+            Tensor& dst = idx < 0 ? *h_mid : (*hs)[idx];
+            if (idx >= 0 && only_mid) return FGDM_OK;
+            e.scale = scales ? scales[idx < 0 ? (int)n.input.size() : idx] : 1.f;
+            e.resid = dst.p; e.ld_res = dst.C; e.out = dst.p; e.ld_out = dst.C;
+            return linear(zw, src, e, nullptr);
+        };
+        for (size_t i = 0; i < n.input.size(); ++i) {
+            Tensor nxt;
+            if (i == 0) {
+                // h = conv_in(x) + guided_hint (cldm.py:803-805); a B-sized hint serves both halves of a 2B CFG batch
+                const Layer& l = n.input[0][0];
+                if (n.guided.B == B) {
+                    CHK(block_fwd(n.input[0], x4, false, nullptr, ec, ctx16, n.guided.p, &nxt));
+                } else {
+                    nxt = talloc(B, x4.H, x4.W, l.cout);
+                    if (!nxt.p) return fail(FGDM_ERR_NOMEM, "workspace");
+                    for (int half = 0; half < 2; ++half) {
+                        Tensor xs = x4; xs.B = B / 2; xs.p = x4.p + (size_t)half * xs.numel();
+                        Epi e; e.resid = n.guided.p; e.ld_res = l.cout;
+                        e.out = nxt.p + (size_t)half * (nxt.numel() / 2); e.ld_out = l.cout;
+                        CHK(conv3(l.conv, xs, nullptr, 1, false, e, nullptr));
+                    }
+                }
+            } else {
+                CHK(block_fwd(n.input[i], h, true, nullptr, ec, ctx16, nullptr, &nxt));
+            }
+            h = nxt;
+            CHK(zero_conv(n.zero_convs[i], h, (int)i));
+        }
+        Tensor m;
+        CHK(block_fwd(n.middle, h, true, nullptr, ec, ctx16, nullptr, &m));
+        CHK(zero_conv(n.mid_out, m, -1));
+        tfree(m);
+        arena.release(emb);
+        return FGDM_OK;
+    }
+
+    int apply_model(const float* x, const int64_t* t, const float* ctx, const float* pcond, const float* scales,
+                    int B, int H, int W, int flags, float* eps_out) {
+        if (!finalized) return fail(FGDM_ERR_STATE, "weights not finalized");
+        if (B <= 0 || H <= 0 || W <= 0) return fail(FGDM_ERR_ARG, "bad shape");
+        Net& n = unet;
+        const int HW = H * W;
+        Tensor x4 = talloc(B, H, W, 4), ctx16 = talloc(B, 1, 77, cfg.context_dim);
+        if (!x4.p || !ctx16.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (nchw_f32_to_nhwc_f16(x, x4.p, B, 4, HW, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
+        if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
+        float* emb = nullptr;
+        CHK(embed(n, t, B, &emb));
+        EmbCtx ec{emb, n.emb_total};
+
+        const bool use_adapter = n.has_adapter && !(flags & FGDM_FLAG_USE_ORIGINAL);
+        Tensor fa[4];
+        if (use_adapter) {
+            if (pcond) {
+                Tensor p4 = talloc(B, H, W, 4);
+                if (!p4.p) return fail(FGDM_ERR_NOMEM, "workspace");
+                if (nchw_f32_to_nhwc_f16(pcond, p4.p, B, 4, HW, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
+                CHK(adapter_fwd(n, p4, fa));
+                tfree(p4);
+            } else {
+                CHK(adapter_fwd(n, x4, fa));
+            }
+        }
+        // ---- encoder (openaimodel.py:849-858); the adapter feature is added BEFORE the skip is recorded
+        std::vector<Tensor> hs;
+        Tensor h;
+        int k = 0;
+        for (size_t i = 0; i < n.input.size(); ++i) {
+            Tensor nxt;
+            CHK(block_fwd(n.input[i], i == 0 ? x4 : h, false, nullptr, ec, ctx16, nullptr, &nxt));
+            if (use_adapter && (i + 1) % 3 == 0) {
+                if (k >= 4 || fa[k].numel() != nxt.numel()) return fail(FGDM_ERR_ARG, "adapter feature shape mismatch (latent size must be divisible by 8)");
+                if (add_f16(nxt.p, fa[k].p, nxt.p, nxt.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
+                tfree(fa[k]);
+                ++k;
+            }
+            h = nxt;
+            hs.push_back(h);
+        }
+        Tensor hm;
+        CHK(block_fwd(n.middle, h, false, nullptr, ec, ctx16, nullptr, &hm));
+        // ---- ControlNets: residuals accumulate in place into hs / hm (cldm.py:40,46,846)
+        if (!cns.empty() && !(flags & FGDM_FLAG_NO_CONTROL)) {
+            for (size_t c = 0; c < cns.size(); ++c)
+                CHK(controlnet_fwd(cns[c], x4, t, ctx16, scales ? scales + 13 * c : nullptr, &hs, &hm,
+                                   (flags & FGDM_FLAG_ONLY_MID_CONTROL) != 0, nullptr, 0));
+        }
+        // ---- decoder (openaimodel.py:868-870): virtual concat [h, skip]
+        h = hm;
+        for (size_t i = 0; i < n.output.size(); ++i) {
+            Tensor skip = hs.back();
+            hs.pop_back();
+            Tensor nxt;
+            CHK(block_fwd(n.output[i], h, true, &skip, ec, ctx16, nullptr, &nxt));
+            tfree(skip);
+            h = nxt;
+        }
+        // ---- out: GN -> SiLU -> conv3x3 (openaimodel.py:724-728) straight to fp32 NCHW
+        Tensor g;
+        CHK(gnorm(n.out_gn, h, nullptr, 1e-5f, true, &g));
+        tfree(h);
+        { Epi e; e.out_kind = OUT_F32_NCHW; e.out = eps_out; e.ld_out = HW; CHK(conv3(n.out_conv, g, nullptr, 1, false, e, nullptr)); }
+        tfree(g);
+        tfree(x4); tfree(ctx16);
+        arena.release(emb);
+        return FGDM_OK;
+    }
+
+    // input_hint_block (cldm.py:655-671): 8 conv3x3, SiLU between, stride 2 at convs 2/4/6; result cached
+    int set_hint(int cn, const float* hint, int B, int Hh, int Wh) {
+        if (!finalized) return fail(FGDM_ERR_STATE, "weights not finalized");
+        if (cn < 0 || cn >= (int)cns.size()) return fail(FGDM_ERR_ARG, "no such ControlNet");
+        if ((Hh & 7) || (Wh & 7) || B <= 0) return fail(FGDM_ERR_ARG, "hint size must be a multiple of 8");
+        Net& n = cns[cn];
+        const int mc = cfg.model_channels, Hl = Hh / 8, Wl = Wh / 8;
+        if (n.guided.p && (n.guided.B != B || n.guided.H != Hl || n.guided.W != Wl)) { (void)hipFree(n.guided.p); n.guided.p = nullptr; }
+        if (!n.guided.p) {
+            n.guided.B = B; n.guided.H = Hl; n.guided.W = Wl; n.guided.C = mc;
+            if (hipMalloc(&n.guided.p, n.guided.numel() * sizeof(half_t)) != hipSuccess) return fail(FGDM_ERR_NOMEM, "hipMalloc (hint cache)");
+        }
+        const int hc = n.hint_convs[0].cin_pad;   // 3 -> 4
+        const int chunk = std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)Hh * Wh * 192 * 2 + 1))));
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = std::min(chunk, B - b0);
+            Tensor cur = talloc(nb, Hh, Wh, hc);
+            if (!cur.p) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (nchw_f32_to_nhwc_f16(hint + (size_t)b0 * cfg.hint_channels * Hh * Wh, cur.p, nb, cfg.hint_channels, Hh * Wh, hc, s) != FGDM_OK)
+                return fail(FGDM_ERR_HIP, "layout kernel");
+            for (int k = 0; k < 8; ++k) {
+                const int stride = (k == 2 || k == 4 || k == 6) ? 2 : 1;
+                Epi e;
+                e.act = k < 7 ? ACT_SILU : ACT_NONE;
+                Tensor nxt;
+                if (k == 7) { e.out = n.guided.p + (size_t)b0 * Hl * Wl * mc; e.ld_out = mc; }
+                CHK(conv3(n.hint_convs[k], cur, nullptr, stride, false, e, k == 7 ? nullptr : &nxt));
+                tfree(cur);
+                cur = nxt;
+            }
+        }
+        return FGDM_OK;
+    }
+};
+
+// ================================================================================================ C ABI
+static hipStream_t as_stream(void* p) { return (hipStream_t)p; }
+
+struct TmpDev {
+    std::vector<void*> ptrs;
+    ~TmpDev() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T> T* up(const std::vector<T>& h) {
+        T* d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(h.size() * sizeof(T), 256)) != hipSuccess) return nullptr;
+        (void)hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+        ptrs.push_back(d);
+        return d;
+    }
+};
+static half_t* g_zero_page() {
+    static half_t* z = nullptr;
+    if (!z) { if (hipMalloc(&z, 4096) != hipSuccess) return nullptr; (void)hipMemset(z, 0, 4096); }
+    return z;
+}
+
+
+static int make_desc(const fgdm_config* cfg, fgdm_engine** out) {
+    fgdm_engine* e = new fgdm_engine();
+    e->cfg = *cfg;
+    const int rc = e->build();
+    if (rc != FGDM_OK) { delete e; return rc; }
+    *out = e;
+    return FGDM_OK;
+}
+
+extern "C" {
+
+int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
+    if (!cfg || !out) return FGDM_ERR_ARG;
+    fgdm_engine* e = nullptr;
+    int rc = make_desc(cfg, &e);
+    if (rc != FGDM_OK) return rc;
+    e->device = device;
+    rc = e->ensure_device();
+    if (rc != FGDM_OK) { delete e; return rc; }
+    *out = e;
+    return FGDM_OK;
+}
+
+void fgdm_destroy(fgdm_engine* e) {
+    if (!e) return;
+    for (void* p : e->weight_allocs) (void)hipFree(p);
+    if (e->zero) (void)hipFree(e->zero);
+    for (auto& n : e->cns) if (n.guided.p) (void)hipFree(n.guided.p);
+    delete e;
+}
+
+const char* fgdm_last_error(const fgdm_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+static fgdm_engine* g_desc = nullptr;
+static fgdm_config g_desc_cfg;
+static fgdm_engine* desc_for(const fgdm_config* cfg) {
+    if (g_desc && memcmp(&g_desc_cfg, cfg, sizeof(*cfg)) == 0) return g_desc;
+    if (g_desc) { delete g_desc; g_desc = nullptr; }
+    if (make_desc(cfg, &g_desc) != FGDM_OK) return nullptr;
+    g_desc_cfg = *cfg;
+    return g_desc;
+}
+int fgdm_param_count(const fgdm_config* cfg) {
+    if (!cfg) return FGDM_ERR_ARG;
+    fgdm_engine* d = desc_for(cfg);
+    return d ? (int)d->order.size() : FGDM_ERR_ARG;
+}
+int fgdm_param_info(const fgdm_config* cfg, int index, char* name, int name_cap, int64_t* shape, int* ndim) {
+    if (!cfg || !name || !shape || !ndim) return FGDM_ERR_ARG;
+    fgdm_engine* d = desc_for(cfg);
+    if (!d || index < 0 || index >= (int)d->order.size()) return FGDM_ERR_ARG;
+    const std::string& n = d->order[index];
+    if ((int)n.size() + 1 > name_cap) return FGDM_ERR_ARG;
+    memcpy(name, n.c_str(), n.size() + 1);
+    const auto& sh = d->params[n].shape;
+    *ndim = (int)sh.size();
+    for (size_t i = 0; i < sh.size(); ++i) shape[i] = sh[i];
+    return FGDM_OK;
+}
+
+int fgdm_load_tensor(fgdm_engine* e, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !key || !data || !shape) return FGDM_ERR_ARG;
+    auto it = e->params.find(key);
+    if (it == e->params.end()) return e->fail(FGDM_ERR_ARG, std::string("unknown parameter key: ") + key);
+    ParamSlot& ps = it->second;
+    if ((int)ps.shape.size() != ndim) return e->fail(FGDM_ERR_ARG, std::string("rank mismatch for ") + key);
+    for (int i = 0; i < ndim; ++i)
+        if (ps.shape[i] != shape[i]) return e->fail(FGDM_ERR_ARG, std::string("shape mismatch for ") + key);
+    const size_t n = ps.numel();
+    ps.host.resize(n);
+    if (dtype == FGDM_DTYPE_F32) {
+        if (hipMemcpy(ps.host.data(), data, n * sizeof(float), hipMemcpyDefault) != hipSuccess) return e->fail(FGDM_ERR_HIP, "hipMemcpy failed");
+    } else if (dtype == FGDM_DTYPE_F16) {
+        std::vector<half_t> tmp(n);
+        if (hipMemcpy(tmp.data(), data, n * sizeof(half_t), hipMemcpyDefault) != hipSuccess) return e->fail(FGDM_ERR_HIP, "hipMemcpy failed");
+        for (size_t i = 0; i < n; ++i) ps.host[i] = (float)tmp[i];
+    } else {
+        return e->fail(FGDM_ERR_ARG, "unsupported dtype");
+    }
+    ps.loaded = true;
+    e->finalized = false;
+    return FGDM_OK;
+}
+
+int fgdm_finalize_weights(fgdm_engine* e) {
+    if (!e) return FGDM_ERR_ARG;
+    int rc = e->ensure_device();
+    if (rc != FGDM_OK) return rc;
+    rc = e->pack_net(e->unet);
+    if (rc != FGDM_OK) return rc;
+    for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }
+    e->finalized = true;
+    return FGDM_OK;
+}
+
+int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int Wh, void* stream) {
+    if (!e || !hint) return FGDM_ERR_ARG;
+    e->s = as_stream(stream);
+    return e->set_hint(cn, hint, B, Hh, Wh);
+}
+
+int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* ctx, const float* pcond,
+                     const float* control_scales, int B, int H, int W, int flags, float* eps_out, void* stream) {
+    if (!e || !x || !t || !ctx || !eps_out) return FGDM_ERR_ARG;
+    e->s = as_stream(stream);
+    return e->apply_model(x, t, ctx, pcond, control_scales, B, H, W, flags, eps_out);
+}
+
+int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, const float* ctx, int B, int H, int W,
+                    float* out, int64_t out_capacity_floats, void* stream) {
+    if (!e || !x || !t || !ctx || !out) return FGDM_ERR_ARG;
+    if (!e->finalized) return e->fail(FGDM_ERR_STATE, "weights not finalized");
+    if (cn < 0 || cn >= (int)e->cns.size()) return e->fail(FGDM_ERR_ARG, "no such ControlNet");
+    e->s = as_stream(stream);
+    Tensor x4 = e->talloc(B, H, W, 4), ctx16 = e->talloc(B, 1, 77, e->cfg.context_dim);
+    if (!x4.p || !ctx16.p) return e->fail(FGDM_ERR_NOMEM, "workspace");
+    if (nchw_f32_to_nhwc_f16(x, x4.p, B, 4, H * W, 4, e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "layout kernel");
+    if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "convert kernel");
+    const int rc = e->controlnet_fwd(e->cns[cn], x4, t, ctx16, nullptr, nullptr, nullptr, false, out, out_capacity_floats);
+    e->tfree(x4); e->tfree(ctx16);
+    return rc;
+}
+
+int fgdm_ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale, float a_t, float a_prev,
+                   float sigma_t, float sqrt_one_minus_at, const float* noise, float* x_prev, float* pred_x0,
+                   float* e_out, int64_t n, void* stream) {
+    if (!x || !e_cond || n <= 0) return FGDM_ERR_ARG;
+    return ddim_step(x, e_cond, e_uncond, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise, x_prev, pred_x0,
+                     e_out, (size_t)n, as_stream(stream));
+}
+int fgdm_plms_combine(const float* e_t, const float* e1, const float* e2, const float* e3, int order, float* e_prime,
+                      int64_t n, void* stream) {
+    if (!e_t || !e_prime || n <= 0) return FGDM_ERR_ARG;
+    return plms_combine(e_t, e1, e2, e3, order, e_prime, (size_t)n, as_stream(stream));
+}
+int fgdm_axpby(const float* a, float ca, const float* b, float cb, float* y, int64_t n, void* stream) {
+    if (!a || !y || n <= 0) return FGDM_ERR_ARG;
+    return axpby(a, ca, b, cb, y, (size_t)n, as_stream(stream));
+}
+int fgdm_ancestral_step(const float* x, const float* eps, float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1,
+                        float coef2, float std, const float* noise, float* out, int64_t n, void* stream) {
+    if (!x || !eps || !out || n <= 0) return FGDM_ERR_ARG;
+    return ancestral_step(x, eps, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, std, noise, out, (size_t)n, as_stream(stream));
+}
+
+int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* uncond, float cfg_scale, int S,
+                     const int64_t* timesteps, const float* alphas, const float* alphas_prev,
+                     const float* sqrt_one_minus_alphas, const float* control_scales, int B, int H, int W, int flags,
+                     void* stream) {
+    if (!e || !x || !cond || !timesteps || !alphas || !alphas_prev || !sqrt_one_minus_alphas || S <= 0) return FGDM_ERR_ARG;
+    if (!e->finalized) return e->fail(FGDM_ERR_STATE, "weights not finalized");
+    hipStream_t s = as_stream(stream);
+    e->s = s;
+    const bool cfg_on = uncond && cfg_scale != 1.0f;
+    const int Bm = cfg_on ? 2 * B : B;
+    const size_t n = (size_t)B * 4 * H * W, nctx = (size_t)B * 77 * e->cfg.context_dim;
+    float* x2 = (float*)e->arena.alloc(Bm * 4 * (size_t)H * W * sizeof(float));
+    float* eps = (float*)e->arena.alloc(Bm * 4 * (size_t)H * W * sizeof(float));
+    float* c2 = (float*)e->arena.alloc(Bm * 77 * (size_t)e->cfg.context_dim * sizeof(float));
+    int64_t* tdev = (int64_t*)e->arena.alloc((size_t)S * Bm * sizeof(int64_t));
+    if (!x2 || !eps || !c2 || !tdev) return e->fail(FGDM_ERR_NOMEM, "workspace");
+    std::vector<int64_t> th((size_t)S * Bm);
+    for (int i = 0; i < S; ++i) for (int b = 0; b < Bm; ++b) th[(size_t)i * Bm + b] = timesteps[i];
+    HIP_TRY(hipMemcpyAsync(tdev, th.data(), th.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // th is a local: the copy must finish before it goes out of scope
+    if (cfg_on) {   // c_in = cat([uncond, cond])  (ddim.py:226)
+        HIP_TRY(hipMemcpyAsync(c2, uncond, nctx * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c2 + nctx, cond, nctx * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c2, cond, nctx * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    int rc = FGDM_OK;
+    for (int i = 0; i < S && rc == FGDM_OK; ++i) {
+        const int index = S - 1 - i;   // reversed walk (ddim.py:137,148)
+        HIP_TRY(hipMemcpyAsync(x2, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (cfg_on) HIP_TRY(hipMemcpyAsync(x2 + n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        rc = e->apply_model(x2, tdev + (size_t)index * Bm, c2, nullptr, control_scales, Bm, H, W, flags, eps);
+        if (rc != FGDM_OK) break;
+        rc = ddim_step(x, cfg_on ? eps + n : eps, cfg_on ? eps : nullptr, cfg_scale, alphas[index], alphas_prev[index], 0.f,
+                       sqrt_one_minus_alphas[index], nullptr, x, nullptr, nullptr, n, s);
+    }
+    e->arena.release(x2); e->arena.release(eps); e->arena.release(c2); e->arena.release(tdev);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ op-level test entries
+int fgdm_op_conv2d(const void* x0, int C0, const void* x1, int C1, const float* w, const float* bias, const float* rowvec,
+                   const void* resid, int B, int H, int W, int Cout, int ksize, int stride, int upsample, int act,
+                   float scale, void* out, void* stream) {
+    if (!x0 || !w || !out || (ksize != 1 && ksize != 3)) return FGDM_ERR_ARG;
+    hipStream_t s = as_stream(stream);
+    const int Cin = C0 + C1, taps = ksize * ksize, K = taps * Cin;
+    if (Cin & 63) return FGDM_ERR_ARG;
+    std::vector<float> wh((size_t)Cout * K), bh(Cout, 0.f);
+    if (hipMemcpy(wh.data(), w, wh.size() * sizeof(float), hipMemcpyDefault) != hipSuccess) return FGDM_ERR_HIP;
+    if (bias && hipMemcpy(bh.data(), bias, Cout * sizeof(float), hipMemcpyDefault) != hipSuccess) return FGDM_ERR_HIP;
+    const size_t npad = igemm_npad(Cout);
+    std::vector<half_t> pk(npad * (size_t)K, (half_t)0);
+    std::vector<float> bp(npad, 0.f);
+    for (int n = 0; n < Cout; ++n) {
+        bp[n] = bh[n];
+        for (int tap = 0; tap < taps; ++tap)
+            for (int c = 0; c < Cin; ++c) pk[(size_t)n * K + tap * Cin + c] = (half_t)wh[((size_t)n * Cin + c) * taps + tap];
+    }
+    TmpDev tmp;
+    IgemmArgs a{};
+    a.A0 = (const half_t*)x0; a.C0 = C0; a.A1 = (const half_t*)x1; a.C1 = C1;
+    a.Wt = tmp.up(pk); a.bias = tmp.up(bp);
+    a.zero = g_zero_page();
+    if (!a.Wt || !a.bias || !a.zero) return FGDM_ERR_NOMEM;
+    a.rowvec = rowvec; a.rv_stride = Cout;
+    a.resid = (const half_t*)resid; a.ld_res = Cout;
+    a.B = B; a.H = H; a.W = W;
+    a.Ho = H; a.Wo = W; a.mode = IG_LINEAR;
+    if (ksize == 3) {
+        a.mode = IG_CONV3;
+        if (upsample) { a.Ho = 2 * H; a.Wo = 2 * W; a.mode = IG_CONV3_UP2; }
+        else if (stride == 2) { a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.mode = IG_CONV3_S2; }
+    }
+    a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = K;
+    a.act = act; a.out_kind = OUT_F16; a.out = out; a.ld_out = Cout;
+    a.rows_per_sample = a.Ho * a.Wo; a.scale = scale;
+    const int rc = igemm_launch(a, s);
+    (void)hipStreamSynchronize(s);   // temporaries are freed on return
+    return rc;
+}
+
+int fgdm_op_linear(const void* x, const float* w, const float* bias, const void* resid, int M, int K, int N, int act,
+                   int out_kind, int rows_per_sample, int ld_out, void* out, void* stream) {
+    if (!x || !w || !out || (K & 63)) return FGDM_ERR_ARG;
+    hipStream_t s = as_stream(stream);
+    std::vector<float> wh((size_t)N * K), bh(N, 0.f);
+    if (hipMemcpy(wh.data(), w, wh.size() * sizeof(float), hipMemcpyDefault) != hipSuccess) return FGDM_ERR_HIP;
+    if (bias && hipMemcpy(bh.data(), bias, N * sizeof(float), hipMemcpyDefault) != hipSuccess) return FGDM_ERR_HIP;
+    const size_t npad = igemm_npad(N);
+    std::vector<half_t> pk(npad * (size_t)K, (half_t)0);
+    std::vector<float> bp(npad, 0.f);
+    for (int pr = 0; pr < N; ++pr) {
+        int sr = pr;
+        if (act == ACT_GEGLU) { const int grp = pr >> 6, within = pr & 63; sr = within < 32 ? grp * 32 + within : N / 2 + grp * 32 + (within - 32); }
+        bp[pr] = bh[sr];
+        for (int k = 0; k < K; ++k) pk[(size_t)pr * K + k] = (half_t)wh[(size_t)sr * K + k];
+    }
+    TmpDev tmp;
+    IgemmArgs a{};
+    a.A0 = (const half_t*)x; a.C0 = K;
+    a.Wt = tmp.up(pk); a.bias = tmp.up(bp); a.zero = g_zero_page();
+    if (!a.Wt || !a.bias || !a.zero) return FGDM_ERR_NOMEM;
+    const int nout = act == ACT_GEGLU ? N / 2 : N;
+    a.resid = (const half_t*)resid; a.ld_res = nout;
+    a.B = 1; a.H = 1; a.W = M; a.Ho = 1; a.Wo = M;
+    a.M = M; a.N = N; a.K = K; a.mode = IG_LINEAR; a.act = act; a.out_kind = out_kind;
+    a.out = out; a.ld_out = ld_out ? ld_out : nout;
+    a.rows_per_sample = rows_per_sample ? rows_per_sample : M; a.scale = 1.f;
+    const int rc = igemm_launch(a, s);
+    (void)hipStreamSynchronize(s);
+    return rc;
+}
+
+int fgdm_op_groupnorm(const void* x0, int C0, const void* x1, int C1, int B, int HW, const float* gamma, const float* beta,
+                      float eps, int silu, void* out, void* stream) {
+    if (!x0 || !gamma || !beta || !out) return FGDM_ERR_ARG;
+    hipStream_t s = as_stream(stream);
+    float* ws = nullptr;
+    if (hipMalloc(&ws, groupnorm_ws_floats(B, HW) * sizeof(float)) != hipSuccess) return FGDM_ERR_NOMEM;
+    const int rc = groupnorm_launch((const half_t*)x0, C0, (const half_t*)x1, C1, B, HW, gamma, beta, eps, silu, (half_t*)out, ws, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(ws);
+    return rc;
+}
+int fgdm_op_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps, void* out, void* stream) {
+    if (!x || !gamma || !beta || !out) return FGDM_ERR_ARG;
+    return layernorm_launch((const half_t*)x, rows, C, gamma, beta, eps, (half_t*)out, as_stream(stream));
+}
+int fgdm_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo, int B,
+                      int heads, int T, int Tk, int d, void* stream) {
+    if (!q || !k || !vt || !o) return FGDM_ERR_ARG;
+    return attention_launch((const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)vt, ldvt, (half_t*)o, ldo, B, heads, T, Tk, d, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,278 @@
+// Implicit-GEMM convolution / linear kernel for gfx950 (CDNA4), fp16 MFMA with fp32 accumulate.
+//
+//   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )
+//   m = output pixel (b, oy, ox) of an NHWC fp16 activation, k = (tap, cin), W packed [N][K] K-contiguous.
+//
+// Covers every dense contraction of the hot path (SURVEY.md section 2 op inventory): conv3x3 s1 / s2, conv3x3 on a
+// nearest-2x-upsampled input (upsample folded into the address calculation), conv1x1 / nn.Linear, and the
+// channel concat of the UNet decoder as two base pointers ("virtual concat").  Epilogue fuses bias, the
+// ResBlock timestep-embedding add, SiLU / ReLU / GEGLU, the ControlNet scale and the residual add.
+//
+// Structure: BK = 64 halfs per K-step; global -> LDS with global_load_lds_dwordx4 (16 B / lane, no VGPR
+// staging); LDS rows are 128 B, XOR-swizzled on the *source* chunk index so that the linear LDS image is
+// conflict-free for ds_read_b128 fragment reads; 2-stage LDS ring, one barrier per K-step; each wave
+// owns a (BM/WM)x(BN/WN) tile of v_mfma_f32_32x32x16_f16 accumulators; XCD-aware block->tile remap.
+#include "common.h"
+
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) {
+    constexpr int T = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int A_IT = BM * 8 / T, B_IT = BN * 8 / T;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the thread count");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+    // range of tiles with the N tiles of one M tile adjacent, so A rows and the weight panel stay L2-hot.
+    const int ntn = (a.N + BN - 1) / BN;
+    const int nb = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
+
+    const int Ctot = a.C0 + a.C1;
+    const int cpt = Ctot >> 6;   // 64-wide chunks per tap
+    const int nk = a.K >> 6;
+
+    // ---- per-thread A row descriptors (fixed for the whole K loop)
+    int a_pix[A_IT], a_yx[A_IT], a_co[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int q = j * T + tid, r = q >> 3, s = q & 7;
+        a_co[j] = ((s ^ ((r >> 1) & 7)) << 3);   // source chunk (halfs) that lands in LDS slot s of row r
+        const int m = m0 + r;
+        a_pix[j] = -1;
+        a_yx[j] = 0;
+        if (m < a.M) {
+            if (a.mode == IG_LINEAR) {
+                a_pix[j] = m;
+            } else {
+                const int hw = a.Ho * a.Wo;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                a_pix[j] = b * a.H * a.W;
+                a_yx[j] = (oy << 16) | ox;
+            }
+        }
+    }
+    int b_off[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int q = j * T + tid, r = q >> 3, s = q & 7;
+        b_off[j] = (n0 + r) * a.K + ((s ^ ((r >> 1) & 7)) << 3);
+    }
+
+    auto stage = [&](int kt, int tap, int cc, int buf) {
+        char* As = smem + buf * STAGE;
+        char* Bs = As + A_BYTES;
+        const half_t* src = a.A0;
+        int Cs = a.C0, co = cc << 6;
+        if (co >= a.C0) { src = a.A1; Cs = a.C1; co -= a.C0; }
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const half_t* p = a.zero;
+            if (a_pix[j] >= 0) {
+                if (a.mode == IG_LINEAR) {
+                    p = src + (size_t)a_pix[j] * Cs + co + a_co[j];
+                } else {
+                    const int oy = a_yx[j] >> 16, ox = a_yx[j] & 0xffff;
+                    int iy, ix;
+                    bool ok;
+                    if (a.mode == IG_CONV3) {
+                        iy = oy + ky - 1; ix = ox + kx - 1;
+                        ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    } else if (a.mode == IG_CONV3_S2) {
+                        iy = 2 * oy + ky - 1; ix = 2 * ox + kx - 1;
+                        ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    } else {   // IG_CONV3_UP2: conv over the virtual 2H x 2W nearest-upsampled image
+                        const int uy = oy + ky - 1, ux = ox + kx - 1;
+                        ok = (unsigned)uy < (unsigned)(2 * a.H) && (unsigned)ux < (unsigned)(2 * a.W);
+                        iy = uy >> 1; ix = ux >> 1;
+                    }
+                    if (ok) p = src + (size_t)(a_pix[j] + iy * a.W + ix) * Cs + co + a_co[j];
+                }
+            }
+            glds16(p, As + (j * T + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j)
+            glds16(a.Wt + (size_t)b_off[j] + ((size_t)kt << 6), Bs + (j * T + wave * 64) * 16);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: row = 32*tile + (lane & 31); (row >> 1) & 7 depends on the lane only
+    const int lrow = lane & 31, lh = lane >> 5, swz = (lrow >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = lrow * 128 + (((ks * 2 + lh) ^ swz) << 4);
+
+    int tap = 0, cc = 0;
+    stage(0, 0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // tile kt has landed for every wave; buffer (kt+1)&1 is no longer being read
+        if (kt + 1 < nk) {
+            if (++cc == cpt) { cc = 0; ++tap; }
+            stage(kt + 1, tap, cc, (kt + 1) & 1);
+        }
+        const char* As = smem + (kt & 1) * STAGE + (wm * TM) * 128;
+        const char* Bs = smem + (kt & 1) * STAGE + A_BYTES + (wn * TN) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            h8 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const h8*)(As + i * 32 * 128 + koff[ks]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *(const h8*)(Bs + j * 32 * 128 + koff[ks]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int rps = a.rows_per_sample;
+    const bool geglu = (a.act == ACT_GEGLU);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (geglu && (j & 1)) continue;   // gate tiles are consumed together with their value tile
+            const int pcol = n0 + wn * TN + j * 32 + lrow;   // packed column of this lane
+            if (pcol >= a.N) continue;
+            const float bias = a.bias ? a.bias[pcol] : 0.f;
+            float gbias = 0.f;
+            if (geglu) gbias = a.bias ? a.bias[pcol + 32] : 0.f;
+            const int ocol = geglu ? ((pcol >> 6) << 5) + lrow : pcol;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row0 = m0 + wm * TM + i * 32 + 8 * g + 4 * lh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = row0 + e;
+                    float x = acc[i][j][g * 4 + e] + bias;
+                    if (a.rowvec && row < a.M) x += a.rowvec[(size_t)(row / rps) * a.rv_stride + pcol];
+                    if (a.act == ACT_SILU) x = silu_f(x);
+                    else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (geglu) {
+                        if constexpr (NI >= 2) x = x * gelu_f(acc[i][j | 1][g * 4 + e] + gbias);
+                    }
+                    v[e] = x * a.scale;
+                }
+                if (a.out_kind == OUT_F16) {
+                    half_t* o = (half_t*)a.out;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = row0 + e;
+                        if (row < a.M) {
+                            float x = v[e];
+                            if (a.resid) x += (float)a.resid[(size_t)row * a.ld_res + ocol];
+                            o[(size_t)row * a.ld_out + ocol] = (half_t)x;
+                        }
+                    }
+                } else if (a.out_kind == OUT_F32) {
+                    float* o = (float*)a.out;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row0 + e < a.M) o[(size_t)(row0 + e) * a.ld_out + ocol] = v[e];
+                } else {
+                    // transposed outputs: [b][col][t]; ld_out = elements per (b, col) row
+                    const bool vec = ((rps & 3) == 0) && (row0 + 3 < a.M);
+                    if (vec) {
+                        const int b = row0 / rps, t = row0 - b * rps;
+                        const size_t off = ((size_t)b * a.N + ocol) * a.ld_out + t;
+                        if (a.out_kind == OUT_F16_T) {
+                            h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                            *(h4*)((half_t*)a.out + off) = pk;
+                        } else {
+                            f32x4 pk = {v[0], v[1], v[2], v[3]};
+                            *(f32x4*)((float*)a.out + off) = pk;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = row0 + e;
+                            if (row < a.M) {
+                                const int b = row / rps, t = row - b * rps;
+                                const size_t off = ((size_t)b * a.N + ocol) * a.ld_out + t;
+                                if (a.out_kind == OUT_F16_T) ((half_t*)a.out)[off] = (half_t)v[e];
+                                else ((float*)a.out)[off] = v[e];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+size_t igemm_npad(int n) { return (size_t)((n + 127) / 128) * 128; }
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    auto k = igemm_kernel<BM, BN, WM, WN>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(WM * WN * 64), smem, s, a);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}
+
+// Pick the tile shape with the lowest modelled time: waves-of-blocks x tile area / relative efficiency.
+int igemm_launch(const IgemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 63) || (a.C0 & 63) || (a.C1 & 63)) return FGDM_ERR_ARG;
+    if (a.act == ACT_GEGLU && (a.N & 63)) return FGDM_ERR_ARG;
+    struct Cfg { int bm, bn; float eff; int per_cu; };
+    static const Cfg cfgs[] = {{128, 128, 1.00f, 2}, {128, 64, 0.80f, 3}, {64, 64, 0.62f, 4}};
+    int best = 0;
+    float best_cost = 1e30f;
+    for (int i = 0; i < 3; ++i) {
+        const Cfg& c = cfgs[i];
+        const long nblk = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
+        const long slots = 256L * c.per_cu;
+        const float rounds = (float)((nblk + slots - 1) / slots);
+        // a partially filled last round still costs a full tile time, but fewer co-resident blocks run faster
+        const float cost = rounds * c.per_cu * (float)(c.bm * c.bn) / c.eff;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    switch (best) {
+        case 0: return launch_cfg<128, 128, 2, 2>(a, s);
+        case 1: return launch_cfg<128, 64, 2, 2>(a, s);
+        default: return launch_cfg<64, 64, 2, 2>(a, s);
+    }
+}

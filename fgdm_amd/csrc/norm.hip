@@ -1,0 +1,201 @@
+// GroupNorm(32) (+SiLU) and LayerNorm over NHWC / token-major fp16 tensors; fp32 statistics.
+// HBM-bound kernels: 16-byte vector loads/stores, wave-shuffle + LDS reductions, deterministic
+// (fixed-order) partial sums so results do not depend on block scheduling or rank count.
+//
+// Reference semantics: GroupNorm32 (ldm/modules/diffusionmodules/util.py:223-225, eps 1e-5),
+// Normalize (ldm/modules/attention.py:76-77, eps 1e-6), nn.LayerNorm (attention.py:226-228, eps 1e-5).
+#include "common.h"
+
+#define GN_PIX_PER_CHUNK 64
+
+__device__ __forceinline__ const half_t* src_octet(const half_t* x0, int C0, const half_t* x1, int C1,
+                                                   size_t pix, int o) {
+    const int c = o << 3;
+    return c < C0 ? x0 + pix * C0 + c : x1 + pix * C1 + (c - C0);
+}
+
+// partial[b][chunk][32][2] = (sum, sumsq) of group g over the chunk's pixels.
+// Per-thread per-channel sums go to LDS and are reduced in a fixed order (no atomics -> bitwise reproducible).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x0, int C0,
+                                                        const half_t* __restrict__ x1, int C1, int HW,
+                                                        float* __restrict__ partial) {
+    extern __shared__ float red[];   // [PI][C][2]
+    const int C = C0 + C1, P = C >> 3, cpg = C >> 5;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int tid = threadIdx.x;
+    const int p_begin = chunk * GN_PIX_PER_CHUNK;
+    const int p_end = min(HW, p_begin + GN_PIX_PER_CHUNK);
+    // thread -> (pixel lane, octet); P <= 256: one octet per thread, several pixel lanes;
+    // P > 256: one pixel lane, up to two octets per thread
+    const int PI = P <= 256 ? 256 / P : 1;
+    const int nslot = P <= 256 ? 1 : 2;
+    for (int slot = 0; slot < nslot; ++slot) {
+        int o, pi;
+        bool active;
+        if (P <= 256) { o = tid % P; pi = tid / P; active = pi < PI; }
+        else { o = tid + slot * 256; pi = 0; active = o < P; }
+        if (active) {
+            float s[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+            for (int p = p_begin + pi; p < p_end; p += PI) {
+                const h8 v = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + p, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[((size_t)pi * C + (o << 3) + e) * 2] = s[e];
+                red[((size_t)pi * C + (o << 3) + e) * 2 + 1] = q[e];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int g = tid >> 1, which = tid & 1;
+        float acc = 0.f;
+        for (int pi = 0; pi < PI; ++pi)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += red[((size_t)pi * C + c) * 2 + which];
+        partial[((size_t)b * nchunk + chunk) * 64 + tid] = acc;
+    }
+}
+
+// stats[b][g] = (mean, rstd)
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, float inv_count, float eps,
+                                   float* __restrict__ stats) {
+    const int b = blockIdx.x, g = threadIdx.x;
+    if (g >= 32) return;
+    // double accumulation: the E[x^2] - mean^2 form must not lose digits when |mean| >> std
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+        s += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2];
+        q += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2 + 1];
+    }
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(b * 32 + g) * 2] = (float)mean;
+    stats[(b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x0, int C0,
+                                                        const half_t* __restrict__ x1, int C1, int HW,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int silu,
+                                                        half_t* __restrict__ out) {
+    extern __shared__ float sc[];   // scale[C], shift[C]
+    const int C = C0 + C1, P = C >> 3, cpg = C >> 5;
+    const int b = blockIdx.y;
+    float* scale = sc;
+    float* shift = sc + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const float mean = stats[(b * 32 + g) * 2], rstd = stats[(b * 32 + g) * 2 + 1];
+        const float w = gamma[c] * rstd;
+        scale[c] = w;
+        shift[c] = beta[c] - mean * w;
+    }
+    __syncthreads();
+    const size_t total = (size_t)HW * P;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t p = i / P;
+        const int o = (int)(i - p * P);
+        const h8 v = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + p, o);
+        h8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (o << 3) + e;
+            float f = (float)v[e] * scale[c] + shift[c];
+            if (silu) f = f / (1.0f + __expf(-f));
+            r[e] = (half_t)f;
+        }
+        *(h8*)(out + ((size_t)b * HW + p) * C + (o << 3)) = r;
+    }
+}
+
+size_t groupnorm_ws_floats(int B, int HW) {
+    const int nchunk = (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK;
+    return (size_t)B * nchunk * 64 + (size_t)B * 64;
+}
+
+int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, int HW, const float* gamma,
+                     const float* beta, float eps, int silu, half_t* out, float* ws, hipStream_t s) {
+    const int C = C0 + C1;
+    if ((C & 31) || (C0 & 7) || (C1 & 7) || C > 4096 || B <= 0 || HW <= 0) return FGDM_ERR_ARG;
+    const int nchunk = (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK;
+    float* partial = ws;
+    float* stats = ws + (size_t)B * nchunk * 64;
+    const int P = C >> 3, PI = P <= 256 ? 256 / P : 1;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), (size_t)PI * C * 2 * sizeof(float), s, x0, C0, x1,
+                       C1, HW, partial);
+    const float inv_count = 1.0f / ((float)HW * (float)(C / 32));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, partial, nchunk, inv_count, eps, stats);
+    const size_t total = (size_t)HW * (C >> 3);
+    int gx = (int)((total + 255) / 256);
+    if (gx > 2048 / (B < 8 ? B : 8)) gx = 2048 / (B < 8 ? B : 8);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), 2 * C * sizeof(float), s, x0, C0, x1, C1, HW,
+                       stats, gamma, beta, silu, out);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}
+
+// ---------------------------------------------------------------- LayerNorm: one wave per token row
+template <int NO>   // octets per lane: C <= NO * 512
+__global__ __launch_bounds__(256) void ln_kernel(const half_t* __restrict__ x, int rows, int C,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float eps, half_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int P = C >> 3;
+    h8 v[NO];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        const int o = lane + k * 64;
+        if (o < P) {
+            v[k] = *(const h8*)(x + (size_t)row * C + (o << 3));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[k][e];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        const int o = lane + k * 64;
+        if (o < P) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[k][e] - mean; sq += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        const int o = lane + k * 64;
+        if (o < P) {
+            h8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = (o << 3) + e;
+                r[e] = (half_t)(((float)v[k][e] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *(h8*)(out + (size_t)row * C + (o << 3)) = r;
+        }
+    }
+}
+
+int layernorm_launch(const half_t* x, int rows, int C, const float* gamma, const float* beta, float eps,
+                     half_t* out, hipStream_t s) {
+    if ((C & 7) || C > 2048 || rows <= 0) return FGDM_ERR_ARG;
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (C <= 512) hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
+    else if (C <= 1024) hipLaunchKernelGGL(ln_kernel<2>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
+    else hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}

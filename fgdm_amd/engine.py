@@ -1,0 +1,286 @@
+"""Python handle on the HIP engine (libfgdm_hip.so).  torch is used only as a container for device
+memory and for the current HIP stream; all arithmetic happens in the hand-written kernels."""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SD_V1 = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1),
+             num_res_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
+
+
+def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, workspace_bytes=0):
+    """fgdm_config from the reference's UNetModel kwargs (models/config.yaml:33-48)."""
+    cfg = dict(SD_V1 if cfg is None else cfg)
+    c = _lib.FgdmConfig()
+    c.in_channels = cfg['in_channels']
+    c.out_channels = cfg['out_channels']
+    c.model_channels = cfg['model_channels']
+    c.num_res_blocks = cfg['num_res_blocks']
+    cm = list(cfg['channel_mult'])
+    ar = list(cfg['attention_resolutions'])
+    c.n_levels = len(cm)
+    for i, v in enumerate(cm):
+        c.channel_mult[i] = v
+    c.n_attention_resolutions = len(ar)
+    for i, v in enumerate(ar):
+        c.attention_resolutions[i] = v
+    c.num_heads = cfg['num_heads']
+    c.context_dim = cfg['context_dim']
+    c.use_adapter = int(bool(use_adapter))
+    c.n_controlnets = int(n_controlnets)
+    c.hint_channels = hint_channels
+    c.workspace_bytes = int(workspace_bytes)
+    return c
+
+
+def param_shapes(config):
+    """OrderedDict state-dict key -> shape the engine expects (no GPU needed)."""
+    lib = _lib.load()
+    n = lib.fgdm_param_count(C.byref(config))
+    if n < 0:
+        raise ValueError(f'fgdm_param_count failed ({n}): unsupported config')
+    out = OrderedDict()
+    name = C.create_string_buffer(256)
+    shape = (C.c_int64 * 8)()
+    ndim = C.c_int()
+    for i in range(n):
+        rc = lib.fgdm_param_info(C.byref(config), i, name, 256, shape, C.byref(ndim))
+        if rc != 0:
+            raise RuntimeError(f'fgdm_param_info({i}) failed: {rc}')
+        out[name.value.decode()] = tuple(int(shape[k]) for k in range(ndim.value))
+    return out
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Engine:
+    """One engine per device: owns packed weights + activation workspace in HBM."""
+
+    def __init__(self, cfg=None, use_adapter=False, n_controlnets=0, device=0, workspace_bytes=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('fgdm_amd.Engine needs a GPU (MI355X); there is no CPU fallback')
+        self.config = make_config(cfg, use_adapter, n_controlnets, workspace_bytes=workspace_bytes)
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.lib.fgdm_create(C.byref(self.config), device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f'fgdm_create failed: {rc}')
+        self.h = h
+        self.n_controlnets = n_controlnets
+        self.use_adapter = bool(use_adapter)
+        self._hint_keys = [None] * n_controlnets
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.fgdm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.fgdm_last_error(self.h)
+            raise RuntimeError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')
+
+    # ------------------------------------------------------------------ weights
+    def param_shapes(self):
+        return param_shapes(self.config)
+
+    def load_tensor(self, key, value):
+        if isinstance(value, torch.Tensor):
+            v = value.detach()
+            if v.dtype not in (torch.float32, torch.float16):
+                v = v.float()
+            v = v.contiguous()
+            dtype = 0 if v.dtype == torch.float32 else 1
+            shape = tuple(v.shape)
+            ptr = C.c_void_p(v.data_ptr())
+            keep = v
+        else:
+            a = np.ascontiguousarray(value)
+            if a.dtype not in (np.float32, np.float16):
+                a = a.astype(np.float32)
+            dtype = 0 if a.dtype == np.float32 else 1
+            shape = a.shape
+            ptr = a.ctypes.data_as(C.c_void_p)
+            keep = a
+        sh = (C.c_int64 * len(shape))(*shape)
+        rc = self.lib.fgdm_load_tensor(self.h, key.encode(), ptr, dtype, sh, len(shape))
+        del keep
+        self._check(rc, f'fgdm_load_tensor({key})')
+
+    def load_state_dict(self, sd, strict=True):
+        """Same keys as the reference checkpoints (model.diffusion_model.*, control_model.*); extra keys
+        (first_stage_model.*, cond_stage_model.* ...) are ignored like load_state_dict(strict=False)."""
+        want = self.param_shapes()
+        missing = [k for k in want if k not in sd]
+        if strict and missing:
+            raise KeyError(f'{len(missing)} parameters missing, e.g. {missing[:3]}')
+        for k in want:
+            if k in sd:
+                self.load_tensor(k, sd[k])
+        return missing
+
+    def finalize(self):
+        self._check(self.lib.fgdm_finalize_weights(self.h), 'fgdm_finalize_weights')
+
+    # ------------------------------------------------------------------ forward
+    def set_hint(self, cn, hint):
+        """hint fp32 NCHW [B,3,8H,8W] in [0,1]; cached until a different tensor is given."""
+        key = (hint.data_ptr(), hint._version, tuple(hint.shape))
+        if self._hint_keys[cn] == key:
+            return
+        hint = hint.to(self.device, torch.float32).contiguous()
+        B, _, Hh, Wh = hint.shape
+        self._check(self.lib.fgdm_set_hint(self.h, cn, _ptr(hint), B, Hh, Wh, _stream()), 'fgdm_set_hint')
+        self._hint_keys[cn] = key
+        self._hint_keep = hint
+
+    def apply_model(self, x, t, ctx, control_scales=None, flags=0, pcond=None, out=None):
+        x = x.to(self.device, torch.float32).contiguous()
+        t = t.to(self.device, torch.int64).contiguous()
+        ctx = ctx.to(self.device, torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        assert Cc == 4 and ctx.shape[0] == B and ctx.shape[1] == 77 and t.shape[0] == B
+        eps = torch.empty_like(x) if out is None else out
+        sc = None
+        if control_scales is not None:
+            sc = torch.as_tensor(control_scales, dtype=torch.float32).flatten()
+            assert sc.numel() == 13 * self.n_controlnets
+            sc_host = sc.numpy().copy()
+            sc_ptr = sc_host.ctypes.data_as(C.c_void_p)
+        else:
+            sc_ptr = C.c_void_p(0)
+        if pcond is not None:
+            pcond = pcond.to(self.device, torch.float32).contiguous()
+        rc = self.lib.fgdm_apply_model(self.h, _ptr(x), _ptr(t), _ptr(ctx), _ptr(pcond), sc_ptr, B, H, W, flags,
+                                       _ptr(eps), _stream())
+        self._check(rc, 'fgdm_apply_model')
+        return eps
+
+    def controlnet(self, cn, x, t, ctx):
+        """The 13 ControlNet residuals (fp32 NCHW), for inspection / tests."""
+        x = x.to(self.device, torch.float32).contiguous()
+        t = t.to(self.device, torch.int64).contiguous()
+        ctx = ctx.to(self.device, torch.float32).contiguous()
+        B, _, H, W = x.shape
+        shapes = self.control_shapes(B, H, W)
+        total = sum(int(np.prod(s)) for s in shapes)
+        buf = torch.empty(total, device=self.device, dtype=torch.float32)
+        rc = self.lib.fgdm_controlnet(self.h, cn, _ptr(x), _ptr(t), _ptr(ctx), B, H, W, _ptr(buf), total, _stream())
+        self._check(rc, 'fgdm_controlnet')
+        outs, off = [], 0
+        for s in shapes:
+            n = int(np.prod(s))
+            outs.append(buf[off:off + n].view(*s))
+            off += n
+        return outs
+
+    def control_shapes(self, B, H, W):
+        c = self.config
+        mc = c.model_channels
+        shapes = [(B, mc, H, W)]
+        ch, h, w = mc, H, W
+        for level in range(c.n_levels):
+            for _ in range(c.num_res_blocks):
+                ch = mc * c.channel_mult[level]
+                shapes.append((B, ch, h, w))
+            if level != c.n_levels - 1:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                shapes.append((B, ch, h, w))
+        shapes.append((B, ch, h, w))
+        return shapes
+
+    def sample_ddim(self, x_T, cond, uncond, cfg_scale, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas,
+                    control_scales=None, flags=0):
+        """Whole eta=0 DDIM loop on the device; returns the final latent (x_T is not modified)."""
+        x = x_T.to(self.device, torch.float32).clone().contiguous()
+        cond = cond.to(self.device, torch.float32).contiguous()
+        if uncond is not None:
+            uncond = uncond.to(self.device, torch.float32).contiguous()
+        B, _, H, W = x.shape
+        S = len(timesteps)
+        ts = (C.c_int64 * S)(*[int(v) for v in timesteps])
+        fa = lambda a: (C.c_float * S)(*[float(v) for v in a])
+        if control_scales is not None:
+            sc_host = np.asarray(control_scales, dtype=np.float32).ravel().copy()
+            sc_ptr = sc_host.ctypes.data_as(C.c_void_p)
+        else:
+            sc_ptr = C.c_void_p(0)
+        rc = self.lib.fgdm_sample_ddim(self.h, _ptr(x), _ptr(cond), _ptr(uncond), float(cfg_scale), S, ts, fa(alphas),
+                                       fa(alphas_prev), fa(sqrt_one_minus_alphas), sc_ptr, B, H, W, flags, _stream())
+        self._check(rc, 'fgdm_sample_ddim')
+        return x
+
+
+# ---------------------------------------------------------------------- fused sampler updates
+def ddim_step(x, e_cond, e_uncond, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise=None,
+              want_pred_x0=True):
+    lib = _lib.load()
+    x_prev = torch.empty_like(x)
+    pred = torch.empty_like(x) if want_pred_x0 else None
+    rc = lib.fgdm_ddim_step(_ptr(x), _ptr(e_cond), _ptr(e_uncond), float(cfg_scale), float(a_t), float(a_prev),
+                            float(sigma_t), float(sqrt_one_minus_at), _ptr(noise), _ptr(x_prev), _ptr(pred),
+                            C.c_void_p(0), x.numel(), _stream())
+    if rc != 0:
+        raise RuntimeError(f'fgdm_ddim_step failed: {rc}')
+    return x_prev, pred
+
+
+def cfg_combine(e_cond, e_uncond, cfg_scale):
+    """e_u + s (e_c - e_u) as its own launch (used by PLMS, which needs e_t before the update)."""
+    lib = _lib.load()
+    e = torch.empty_like(e_cond)
+    rc = lib.fgdm_ddim_step(_ptr(e_cond), _ptr(e_cond), _ptr(e_uncond), float(cfg_scale), 1.0, 1.0, 0.0, 0.0,
+                            C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), _ptr(e), e.numel(), _stream())
+    if rc != 0:
+        raise RuntimeError(f'fgdm_ddim_step(cfg) failed: {rc}')
+    return e
+
+
+def plms_combine(e_t, old_eps):
+    lib = _lib.load()
+    order = len(old_eps)
+    out = torch.empty_like(e_t)
+    e1 = old_eps[-1]
+    e2 = old_eps[-2] if order >= 2 else None
+    e3 = old_eps[-3] if order >= 3 else None
+    rc = lib.fgdm_plms_combine(_ptr(e_t), _ptr(e1), _ptr(e2), _ptr(e3), min(order, 3), _ptr(out), e_t.numel(), _stream())
+    if rc != 0:
+        raise RuntimeError(f'fgdm_plms_combine failed: {rc}')
+    return out
+
+
+def axpby(a, ca, b, cb):
+    lib = _lib.load()
+    y = torch.empty_like(a)
+    rc = lib.fgdm_axpby(_ptr(a), float(ca), _ptr(b), float(cb), _ptr(y), a.numel(), _stream())
+    if rc != 0:
+        raise RuntimeError(f'fgdm_axpby failed: {rc}')
+    return y
+
+
+def ancestral_step(x, eps, sqrt_recip, sqrt_recipm1, coef1, coef2, std, noise=None):
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    rc = lib.fgdm_ancestral_step(_ptr(x), _ptr(eps), float(sqrt_recip), float(sqrt_recipm1), float(coef1),
+                                 float(coef2), float(std), _ptr(noise), _ptr(out), x.numel(), _stream())
+    if rc != 0:
+        raise RuntimeError(f'fgdm_ancestral_step failed: {rc}')
+    return out

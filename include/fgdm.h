@@ -1,0 +1,125 @@
+/* libfgdm_hip.so -- C ABI of the MI355X-native FG-DM sampling engine.
+ *
+ * Drop-in boundary for the hot path named in BASELINE.json.  Each entry point states the
+ * reference interface it replaces (paths relative to the DeepakSridhar/fgdm checkout).  Conventions:
+ *   - return 0 on success, negative FGDM_ERR_* otherwise; nothing throws across the ABI;
+ *     fgdm_last_error() gives a message for the last failing call on that engine;
+ *   - all tensor arguments are DEVICE pointers owned by the caller (e.g. torch tensor.data_ptr()), except
+ *     fgdm_load_tensor which accepts host or device memory;
+ *   - latents / eps are fp32 NCHW [B,4,H,W]; timesteps int64 [B]; context fp32 [B,77,ctx_dim];
+ *     hints fp32 NCHW [B,3,8H,8W] in [0,1];
+ *   - the engine owns weights and workspace; one engine per device; not thread-safe; all work is enqueued on
+ *     the stream passed in (a hipStream_t cast to void*; NULL = default stream), no implicit synchronisation.
+ */
+#ifndef FGDM_H
+#define FGDM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGDM_MAX_LEVELS 8
+#define FGDM_MAX_CONTROLNETS 4
+
+typedef struct fgdm_engine fgdm_engine;
+
+/* Hyper-parameters of UNetModel / ControlNet: the keys of models/config.yaml:33-48 and
+ * controlnet/models/cldm_v15_canny.yaml:21-53 (use_spatial_transformer=True, transformer_depth=1, legacy=False). */
+typedef struct fgdm_config {
+    int32_t in_channels, out_channels, model_channels, num_res_blocks;
+    int32_t n_levels;
+    int32_t channel_mult[FGDM_MAX_LEVELS];
+    int32_t n_attention_resolutions;
+    int32_t attention_resolutions[FGDM_MAX_LEVELS];
+    int32_t num_heads, context_dim;
+    int32_t use_adapter;       /* 1: FG-DM UNet with the self-prompt Adapter (openaimodel.py:554-556) */
+    int32_t n_controlnets;     /* 0..FGDM_MAX_CONTROLNETS ControlNet twin encoders (cldm.py:545-790) */
+    int32_t hint_channels;     /* 3 */
+    int64_t workspace_bytes;   /* initial activation slab; 0 = default; grows on demand */
+} fgdm_config;
+
+#define FGDM_DTYPE_F32 0
+#define FGDM_DTYPE_F16 1
+
+/* flags for fgdm_apply_model */
+#define FGDM_FLAG_USE_ORIGINAL 1      /* UNetModel.forward_original: skip the adapter (openaimodel.py:818-822) */
+#define FGDM_FLAG_ONLY_MID_CONTROL 2  /* ControlledUnetModel only_mid_control (cldm.py:43-44) */
+#define FGDM_FLAG_NO_CONTROL 4        /* cond['c_concat'] is None branch (cldm.py:842-843) */
+
+int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out);
+void fgdm_destroy(fgdm_engine* e);
+const char* fgdm_last_error(const fgdm_engine* e);
+
+/* Parameter table: the reference state_dict keys the engine expects.  UNet keys carry the prefix
+ * "model.diffusion_model." (adapter: "model.diffusion_model.adapter."), ControlNet k uses "control_model."
+ * (k = 0) or "control_model_<k>." -- the names load_state_dict sees at
+ * scripts/txt2img_fgdm_inference.py:23-38 and controlnet/cldm/model.py:12-28.  Works without a GPU. */
+int fgdm_param_count(const fgdm_config* cfg);
+int fgdm_param_info(const fgdm_config* cfg, int index, char* name, int name_cap, int64_t* shape, int* ndim);
+
+/* Replaces load_state_dict: copy one tensor (host or device memory, contiguous) into the engine's staging. */
+int fgdm_load_tensor(fgdm_engine* e, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
+/* Repack all loaded tensors into the kernel layouts (fp16, K-contiguous, GEGLU-interleaved ...) in HBM. */
+int fgdm_finalize_weights(fgdm_engine* e);
+
+/* ControlNet.input_hint_block (cldm.py:655-671,796): t-independent, so computed once per image batch and cached
+ * inside the engine for ControlNet `cn`; the reference recomputes it on every apply_model call. */
+int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int Wh, void* stream);
+
+/* LatentDiffusion.apply_model / DiffusionWrapper.forward -> UNetModel.forward (ldm/models/diffusion/ddpm.py:1035-1136,
+ * 1829-1848; openaimodel.py:808-884) and, when the engine has ControlNets and FGDM_FLAG_NO_CONTROL is not set,
+ * ControlLDM.apply_model (controlnet/cldm/cldm.py:836-849) using the hints cached by fgdm_set_hint:
+ * eps = UNet(x, t, ctx, control = sum_k scales_k * ControlNet_k(x, hint_k, t, ctx)).
+ * control_scales: n_controlnets * 13 floats (cldm.py:823) or NULL for 1.0.  pcond: optional adapter input
+ * (openaimodel.py:838-841) fp32 NCHW or NULL (= x). */
+int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* ctx, const float* pcond,
+                     const float* control_scales, int B, int H, int W, int flags, float* eps_out, void* stream);
+
+/* ControlNet.forward alone (cldm.py:792-813): the 13 residual tensors as fp32 NCHW, written back-to-back into
+ * `out` in the order the reference returns them.  Test/inspection entry; apply_model never materialises them. */
+int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, const float* ctx, int B, int H, int W,
+                    float* out, int64_t out_capacity_floats, void* stream);
+
+/* One fused sampler update on fp32 tensors of n elements.
+ * fgdm_ddim_step: p_sample_ddim's CFG combine + x_prev/pred_x0 (ldm/models/diffusion/ddim.py:243,254-268;
+ * controlnet/cldm/ddim_hacked.py:192,203-231).  e_uncond NULL = no CFG; noise NULL = sigma term skipped;
+ * any of x_prev / pred_x0 / e_out may be NULL. */
+int fgdm_ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale, float a_t,
+                   float a_prev, float sigma_t, float sqrt_one_minus_at, const float* noise, float* x_prev,
+                   float* pred_x0, float* e_out, int64_t n, void* stream);
+/* Adams-Bashforth eps combination of p_sample_plms (ldm/models/diffusion/plms.py:224-232); order 1..3. */
+int fgdm_plms_combine(const float* e_t, const float* e1, const float* e2, const float* e3, int order,
+                      float* e_prime, int64_t n, void* stream);
+/* y = ca*a + cb*b (b may be NULL): the Heun-like first PLMS step (plms.py:219-223) and mask blends (ddim.py:151-154) */
+int fgdm_axpby(const float* a, float ca, const float* b, float cb, float* y, int64_t n, void* stream);
+/* p_sample / p_mean_variance / q_posterior (ldm/models/diffusion/ddpm.py:284-297,1260-1323) for one timestep. */
+int fgdm_ancestral_step(const float* x, const float* eps, float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1,
+                        float coef2, float std, const float* noise, float* out, int64_t n, void* stream);
+
+/* Whole DDIM loop on the device (DDIMSampler.sample with eta = 0 and no host callbacks, ddim.py:58-177;
+ * ddim_hacked.py:55-178).  alphas/alphas_prev/sqrt_one_minus_alphas: S floats (host) in ddim_timesteps order,
+ * timesteps: S int64 (host).  cond/uncond ctx fp32 [B,77,ctx]; uncond NULL or cfg_scale == 1 disables CFG.
+ * CFG runs as ONE 2B batch (cat([uncond, cond]), ddim.py:222-226); x is updated in place. */
+int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* uncond, float cfg_scale, int S,
+                     const int64_t* timesteps, const float* alphas, const float* alphas_prev,
+                     const float* sqrt_one_minus_alphas, const float* control_scales, int B, int H, int W,
+                     int flags, void* stream);
+
+/* Per-kernel entry points used by the parity tests (tests/test_gpu_ops.py); weights given in the reference's
+ * native layouts (fp32, [Cout,Cin,kh,kw] / [N,K]) and packed on the fly.  Activations fp16 NHWC. */
+int fgdm_op_conv2d(const void* x0, int C0, const void* x1, int C1, const float* w, const float* bias,
+                   const float* rowvec, const void* resid, int B, int H, int W, int Cout, int ksize, int stride,
+                   int upsample, int act, float scale, void* out, void* stream);
+int fgdm_op_linear(const void* x, const float* w, const float* bias, const void* resid, int M, int K, int N,
+                   int act, int out_kind, int rows_per_sample, int ld_out, void* out, void* stream);
+int fgdm_op_groupnorm(const void* x0, int C0, const void* x1, int C1, int B, int HW, const float* gamma,
+                      const float* beta, float eps, int silu, void* out, void* stream);
+int fgdm_op_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps,
+                      void* out, void* stream);
+int fgdm_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                      int B, int heads, int T, int Tk, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

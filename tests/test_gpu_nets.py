@@ -1,0 +1,127 @@
+"""Whole-network parity through the C ABI: HIP engine vs golden vectors from the imported reference
+(tests/golden, fp32 CPU) and vs the CPU oracle at full latent size.
+
+Tolerance for one complete UNet / ControlNet evaluation: normwise relative error <= 4e-3.
+Why not 1e-3: rounding ONLY the GEMM operands (weights + inputs) of the fp32 reference to fp16 -- which any
+fp16-MFMA implementation must do -- already moves the output of this 60-layer network by 1.5e-3 (measured with
+the oracle, see DESIGN.md "Numerics"); with fp16 activation storage the emulated floor is 1.7e-3.  Per-kernel
+tests (test_gpu_ops.py) hold the 1e-3 bar."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from common import gold, relerr
+from fgdm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+NET_TOL = 4e-3
+
+
+def build_engine(cfg, rename, use_adapter=False, n_controlnets=0):
+    """Engine with synthetic weights; `rename(engine_key) -> generator key` (the goldens hash names with
+    the prefixes tools/make_goldens.py used)."""
+    from fgdm_amd.engine import Engine
+    e = Engine(cfg, use_adapter=use_adapter, n_controlnets=n_controlnets)
+    for k, shape in e.param_shapes().items():
+        e.load_tensor(k, synth.make_tensor(rename(k), shape))
+    e.finalize()
+    return e
+
+
+@pytest.fixture(scope='module')
+def sd_engine():
+    e = build_engine(gi.SD_CFG, lambda k: k, use_adapter=True, n_controlnets=1)
+    yield e
+    e.close()
+
+
+def small_rename(k):
+    return k.replace('model.diffusion_model.', 'small.').replace('control_model.', 'small_cn.')
+
+
+@pytest.fixture(scope='module')
+def small_engine():
+    e = build_engine(gi.SMALL_CFG, small_rename, n_controlnets=1)
+    yield e
+    e.close()
+
+
+def test_unet_full_width_vs_reference_goldens(sd_engine):
+    from fgdm_amd import _lib
+    g = gold('unet_full')
+    ctx = gi.get('unet/ctx')
+    t = torch.from_numpy(g['t'])
+    for hw in (8, 16):
+        x = gi.get(f'unet/x{hw}')
+        e = sd_engine.apply_model(x, t, ctx, flags=_lib.FLAG_USE_ORIGINAL | _lib.FLAG_NO_CONTROL)
+        assert relerr(e.cpu(), g[f'eps_orig{hw}']) < NET_TOL, ('forward_original', hw)
+        e = sd_engine.apply_model(x, t, ctx, flags=_lib.FLAG_NO_CONTROL)
+        assert relerr(e.cpu(), g[f'eps_fgdm{hw}']) < NET_TOL, ('FG-DM adapter path', hw)
+
+
+def test_controlnet_full_width_vs_reference_goldens():
+    from fgdm_amd import _lib
+    # ControlledUnetModel has no adapter: separate engine without it (keys identical to the golden's)
+    e = build_engine(gi.SD_CFG, lambda k: k, use_adapter=False, n_controlnets=1)
+    try:
+        g = gold('controlnet_full')
+        ctx, x = gi.get('cn/ctx'), gi.get('cn/x')
+        t = torch.from_numpy(g['t'])
+        e.set_hint(0, gi.hint(2, 64, 45).cuda())
+        ctrl = e.controlnet(0, x, t, ctx)
+        assert len(ctrl) == 13
+        for i, c in enumerate(ctrl):
+            assert tuple(c.shape) == g[f'ctrl{i}'].shape
+            assert relerr(c.cpu(), g[f'ctrl{i}']) < NET_TOL, i
+        eps = e.apply_model(x, t, ctx, control_scales=gi.CTRL_SCALES)
+        assert relerr(eps.cpu(), g['eps_ctrl']) < NET_TOL
+        eps = e.apply_model(x, t, ctx, flags=_lib.FLAG_NO_CONTROL)
+        assert relerr(eps.cpu(), g['eps_noctrl']) < NET_TOL
+        # hint block alone: a zero latent/ctx isolates it?  No -- check through the public cache instead:
+        # the cached guided hint feeds ctrl0 (= zero_conv0(conv_in(x) + guided)), already covered above.
+    finally:
+        e.close()
+
+
+def test_reduced_nets_at_full_latent_size(small_engine):
+    from fgdm_amd import _lib
+    g = gold('small_nets')
+    ctx, x = gi.get('small/ctx'), gi.get('small/x')
+    t = torch.from_numpy(g['t'])
+    e = small_engine.apply_model(x, t, ctx, flags=_lib.FLAG_NO_CONTROL)
+    assert relerr(e.cpu(), g['eps_small']) < NET_TOL
+    small_engine.set_hint(0, gi.hint(2, 512, 47).cuda())
+    e = small_engine.apply_model(x, t, ctx)
+    assert relerr(e.cpu(), g['eps_small_ctrl']) < NET_TOL
+
+
+def test_batch_rows_are_independent_and_deterministic(small_engine):
+    """Sharding invariant: a sample's eps does not depend on its batch neighbours or position,
+    bit for bit -- this is what makes N-rank results identical to 1-rank results."""
+    from fgdm_amd import _lib
+    x = torch.from_numpy(synth.latents(4, 32, 32, seed=5))
+    ctx = torch.from_numpy(synth.context(4, seed=6))
+    t = torch.tensor([500, 500, 500, 500])
+    f = _lib.FLAG_NO_CONTROL
+    full = small_engine.apply_model(x, t, ctx, flags=f).cpu()
+    again = small_engine.apply_model(x, t, ctx, flags=f).cpu()
+    assert torch.equal(full, again)
+    lo = small_engine.apply_model(x[:2], t[:2], ctx[:2], flags=f).cpu()
+    hi = small_engine.apply_model(x[2:], t[2:], ctx[2:], flags=f).cpu()
+    assert torch.equal(full[:2], lo) and torch.equal(full[2:], hi)
+
+
+def test_ddim_trajectory_vs_reference_sampler(small_engine):
+    """End-to-end compounding: 10 DDIM steps with CFG 7.5 on a 16x16 latent, reference DDIMSampler + reference
+    UNet (golden) vs the device-side loop.  Errors accumulate over 20 network evaluations -> 1e-2."""
+    from fgdm_amd import _lib
+    from oracle import schedule
+    g = gold('sampler_unet')
+    sched = schedule.register_schedule()
+    tab = schedule.ddim_tables(sched['alphas_cumprod'], 10, 0.0)
+    out = small_engine.sample_ddim(gi.get('sunet/x_T'), gi.get('sunet/c'), gi.get('sunet/uc'), 7.5,
+                                   tab['timesteps'], tab['alphas'], tab['alphas_prev'], tab['sqrt_one_minus_alphas'],
+                                   flags=_lib.FLAG_NO_CONTROL)
+    assert relerr(out.cpu(), g['out']) < 1e-2

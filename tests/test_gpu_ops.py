@@ -1,0 +1,223 @@
+"""Per-kernel parity: every HIP kernel, called through the C ABI, against the CPU oracle's arithmetic
+(torch fp32 functional on the SAME fp16-rounded inputs and weights).
+
+Tolerance: normwise relative error <= 1e-3 (the north_star's "1e-3 relative fp16 tolerance"); outputs are
+stored in fp16 (unit roundoff 4.9e-4), accumulation is fp32."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from common import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from fgdm_amd import _lib
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return _lib.load()
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def nhwc16(x):   # NCHW fp32 cpu -> NHWC fp16 cuda
+    return x.permute(0, 2, 3, 1).contiguous().half().cuda()
+
+
+def from_nhwc(y, B, H, W, Cc):
+    return y.float().cpu().view(B, H, W, Cc).permute(0, 3, 1, 2)
+
+
+def h16(x):
+    return x.half().float()
+
+
+CONV_CASES = [
+    # B, H, W, C0, C1, Cout, ksize, stride, up, act, extras
+    (2, 16, 16, 320, 0, 320, 3, 1, 0, 0, 'bias+rowvec+resid'),
+    (2, 8, 8, 640, 320, 320, 3, 1, 0, 1, 'concat+silu'),
+    (3, 8, 8, 320, 0, 640, 3, 2, 0, 0, 'stride2, M tail'),
+    (2, 8, 8, 640, 0, 640, 3, 1, 1, 0, 'upsample'),
+    (1, 1, 1, 1280, 0, 1280, 3, 1, 0, 0, '1x1 spatial'),
+    (2, 8, 8, 1280, 640, 1280, 1, 1, 0, 0, 'conv1x1 concat (skip_connection)'),
+    (2, 16, 16, 320, 0, 4, 3, 1, 0, 0, 'N=4 (UNet out conv)'),
+    (1, 64, 64, 320, 0, 320, 3, 1, 0, 2, 'full-res latent, relu'),
+    (2, 7, 5, 64, 0, 96, 3, 2, 0, 0, 'odd sizes'),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[-1] for c in CONV_CASES])
+def test_conv(lib, case):
+    B, H, W, C0, C1, Cout, ks, stride, up, act, tag = case
+    Cin = C0 + C1
+    x = h16(rnd((B, Cin, H, W), 1))
+    w = h16(rnd((Cout, Cin, ks, ks), 2, 1.0 / np.sqrt(Cin * ks * ks)))
+    bias = rnd((Cout,), 3, 0.1)
+    ref_in = F.interpolate(x, scale_factor=2, mode='nearest') if up else x
+    ref = F.conv2d(ref_in, w, bias, stride=stride, padding=ks // 2)
+    Ho, Wo = ref.shape[2:]
+    use_extra = 'rowvec' in tag
+    rowvec = rnd((B, Cout), 4, 0.5) if use_extra else None
+    resid = h16(rnd((B, Cout, Ho, Wo), 5)) if use_extra else None
+    if rowvec is not None:
+        ref = ref + rowvec[:, :, None, None]
+    if act == 1:
+        ref = F.silu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    scale = 0.75 if use_extra else 1.0
+    ref = ref * scale
+    if resid is not None:
+        ref = ref + resid
+    x0 = nhwc16(x[:, :C0])
+    x1 = nhwc16(x[:, C0:]) if C1 else None
+    out = torch.empty(B * Ho * Wo * Cout, dtype=torch.half, device='cuda')
+    rc = lib.fgdm_op_conv2d(_p(x0), C0, _p(x1), C1, _p(w.cuda()), _p(bias.cuda()),
+                            _p(rowvec.cuda() if rowvec is not None else None),
+                            _p(nhwc16(resid) if resid is not None else None),
+                            B, H, W, Cout, ks, stride, up, act, scale, _p(out), _st())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = from_nhwc(out, B, Ho, Wo, Cout)
+    assert relerr(got, ref) < TOL, tag
+
+
+def test_linear_variants(lib):
+    M, K, N = 200, 320, 2560
+    x = h16(rnd((M, K), 11))
+    w = h16(rnd((N, K), 12, 1 / np.sqrt(K)))
+    b = rnd((N,), 13, 0.1)
+    # GEGLU (ldm/modules/attention.py:37-44): value * gelu(gate), gate = second half of the projection
+    y = F.linear(x, w, b)
+    a, g = y.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    out = torch.empty(M, N // 2, dtype=torch.half, device='cuda')
+    assert lib.fgdm_op_linear(_p(x.half().cuda()), _p(w.cuda()), _p(b.cuda()), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
+    assert relerr(out.float().cpu(), ref) < TOL
+    # plain + residual, fp32 output, transposed fp16 output (V^T for attention), ragged rows-per-sample (77)
+    N2 = 320
+    w2, b2 = w[:N2].contiguous(), b[:N2].contiguous()
+    ref = F.linear(x, w2, b2)
+    res = h16(rnd((M, N2), 14))
+    out = torch.empty(M, N2, dtype=torch.half, device='cuda')
+    assert lib.fgdm_op_linear(_p(x.half().cuda()), _p(w2.cuda()), _p(b2.cuda()), _p(res.half().cuda()), M, K, N2, 0, 0, 0, 0, _p(out), _st()) == 0
+    assert relerr(out.float().cpu(), ref + res) < TOL
+    out32 = torch.empty(M, N2, dtype=torch.float32, device='cuda')
+    assert lib.fgdm_op_linear(_p(x.half().cuda()), _p(w2.cuda()), _p(b2.cuda()), None, M, K, N2, 0, 1, 0, 0, _p(out32), _st()) == 0
+    assert relerr(out32.cpu(), ref) < 2e-5 + 0 * TOL     # fp32 store: only accumulation-order error
+    for rps, Bt in ((100, 2), (77, 2), (4, 50)):
+        Mt = rps * Bt
+        ld = (rps + 63) // 64 * 64
+        outT = torch.zeros(Bt, N2, ld, dtype=torch.half, device='cuda')
+        assert lib.fgdm_op_linear(_p(x[:Mt].half().cuda()), _p(w2.cuda()), _p(b2.cuda()), None, Mt, K, N2, 0, 3, rps, ld, _p(outT), _st()) == 0
+        want = ref[:Mt].view(Bt, rps, N2).permute(0, 2, 1)
+        assert relerr(outT[:, :, :rps].float().cpu(), want) < TOL
+        assert float(outT[:, :, rps:].abs().max()) == 0.0 if ld > rps else True
+
+
+GN_CASES = [(2, 64, 320, 0, 1e-5, 1), (2, 64, 1280, 640, 1e-5, 1), (1, 16, 1280, 1280, 1e-5, 1),
+            (2, 1, 1280, 0, 1e-6, 0), (3, 4096, 320, 0, 1e-6, 0), (2, 256, 640, 320, 1e-5, 1)]
+
+
+@pytest.mark.parametrize('case', GN_CASES, ids=[f'B{c[0]}_HW{c[1]}_C{c[2]}+{c[3]}' for c in GN_CASES])
+def test_groupnorm(lib, case):
+    B, HW, C0, C1, eps, silu = case
+    Cc = C0 + C1
+    x = h16(rnd((B, Cc, HW, 1), 21) * 2.0 + 0.7)
+    gamma, beta = 1 + 0.2 * rnd((Cc,), 22), 0.1 * rnd((Cc,), 23)
+    ref = F.group_norm(x, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    x0 = nhwc16(x[:, :C0])
+    x1 = nhwc16(x[:, C0:]) if C1 else None
+    out = torch.empty(B * HW * Cc, dtype=torch.half, device='cuda')
+    assert lib.fgdm_op_groupnorm(_p(x0), C0, _p(x1), C1, B, HW, _p(gamma.cuda()), _p(beta.cuda()), eps, silu, _p(out), _st()) == 0
+    assert relerr(from_nhwc(out, B, HW, 1, Cc), ref) < TOL
+
+
+def test_groupnorm_is_bitwise_reproducible(lib):
+    B, HW, Cc = 2, 1024, 640
+    x = nhwc16(rnd((B, Cc, HW, 1), 24))
+    gamma, beta = torch.ones(Cc).cuda(), torch.zeros(Cc).cuda()
+    outs = []
+    for _ in range(3):
+        out = torch.empty(B * HW * Cc, dtype=torch.half, device='cuda')
+        assert lib.fgdm_op_groupnorm(_p(x), Cc, None, 0, B, HW, _p(gamma), _p(beta), 1e-5, 1, _p(out), _st()) == 0
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize('C_', [320, 640, 1280])
+def test_layernorm(lib, C_):
+    rows = 333
+    x = h16(rnd((rows, C_), 31) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.2 * rnd((C_,), 32), 0.1 * rnd((C_,), 33)
+    ref = F.layer_norm(x, (C_,), gamma, beta, 1e-5)
+    out = torch.empty(rows, C_, dtype=torch.half, device='cuda')
+    assert lib.fgdm_op_layernorm(_p(x.half().cuda()), rows, C_, _p(gamma.cuda()), _p(beta.cuda()), 1e-5, _p(out), _st()) == 0
+    assert relerr(out.float().cpu(), ref) < TOL
+
+
+ATT_CASES = [(2, 8, 64, 64, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160),
+             (2, 8, 64, 77, 40), (1, 8, 4096, 77, 40), (2, 8, 256, 77, 160), (2, 8, 1, 1, 160), (2, 8, 16, 16, 80),
+             (1, 4, 200, 130, 80)]
+
+
+@pytest.mark.parametrize('case', ATT_CASES, ids=[f'B{c[0]}_H{c[1]}_T{c[2]}_Tk{c[3]}_d{c[4]}' for c in ATT_CASES])
+def test_attention(lib, case):
+    B, Hh, T, Tk, d = case
+    Cc = Hh * d
+    q, k, v = h16(rnd((B, T, Cc), 41)), h16(rnd((B, Tk, Cc), 42)), h16(rnd((B, Tk, Cc), 43))
+    # spike one key against one query so the running max jumps mid-way (online-softmax rescale branch)
+    if Tk > 70:
+        k[:, 70, :d] = q[:, 0, :d] * 4.0
+    split = lambda t: t.view(B, -1, Hh, d).permute(0, 2, 1, 3)
+    sim = torch.matmul(split(q), split(k).transpose(-1, -2)) * d ** -0.5
+    ref = torch.matmul(sim.softmax(-1), split(v)).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    Tkp = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, Cc, Tkp, dtype=torch.half)
+    vt[:, :, :Tk] = v.permute(0, 2, 1).half()
+    out = torch.empty(B, T, Cc, dtype=torch.half, device='cuda')
+    rc = lib.fgdm_op_attention(_p(q.half().cuda()), Cc, _p(k.half().cuda()), Cc, _p(vt.cuda()), Tkp, _p(out), Cc,
+                               B, Hh, T, Tk, d, _st())
+    assert rc == 0
+    assert relerr(out.float().cpu(), ref) < TOL
+
+
+def test_sampler_kernels(lib):
+    from fgdm_amd import engine as E
+    n = (2, 4, 64, 64)
+    x, ec, eu, nz = (rnd(n, s).cuda() for s in (51, 52, 53, 54))
+    a_t, a_prev, sig = 0.31, 0.42, 0.05
+    s1m = float(np.sqrt(1 - a_t))
+    x_prev, pred = E.ddim_step(x, ec, eu, 7.5, a_t, a_prev, sig, s1m, nz)
+    e = eu + 7.5 * (ec - eu)
+    p0 = (x - s1m * e) / np.sqrt(a_t)
+    xp = np.sqrt(a_prev) * p0 + np.sqrt(1 - a_prev - sig ** 2) * e + sig * nz
+    assert relerr(pred.cpu(), p0.cpu()) < 1e-6 and relerr(x_prev.cpu(), xp.cpu()) < 1e-6
+    assert relerr(E.cfg_combine(ec, eu, 9.0).cpu(), (eu + 9.0 * (ec - eu)).cpu()) < 1e-6
+    olds = [rnd(n, 60 + i).cuda() for i in range(3)]
+    assert relerr(E.plms_combine(ec, olds[-1:]).cpu(), ((3 * ec - olds[-1]) / 2).cpu()) < 1e-6
+    assert relerr(E.plms_combine(ec, olds[-2:]).cpu(), ((23 * ec - 16 * olds[-1] + 5 * olds[-2]) / 12).cpu()) < 1e-6
+    assert relerr(E.plms_combine(ec, olds).cpu(), ((55 * ec - 59 * olds[-1] + 37 * olds[-2] - 9 * olds[-3]) / 24).cpu()) < 1e-6
+    assert relerr(E.axpby(x, 0.5, ec, 0.5).cpu(), ((x + ec) / 2).cpu()) < 1e-6
+    got = E.ancestral_step(x, ec, 1.7, 1.3, 0.2, 0.8, 0.4, nz)
+    x0 = 1.7 * x - 1.3 * ec
+    assert relerr(got.cpu(), (0.2 * x0 + 0.8 * x + 0.4 * nz).cpu()) < 1e-6
