@@ -13,6 +13,7 @@
 // conflict-free for ds_read_b128 fragment reads; 2-stage LDS ring, one barrier per K-step; each wave
 // owns a (BM/WM)x(BN/WN) tile of v_mfma_f32_32x32x16_f16 accumulators; XCD-aware block->tile remap.
 #include "common.h"
+#include <algorithm>
 
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
@@ -266,10 +267,12 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
         const long nblk = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
         const long slots = 256L * c.per_cu;
         const float rounds = (float)((nblk + slots - 1) / slots);
-        // a partially filled last round still costs a full tile time, but fewer co-resident blocks run faster
-        const float cost = rounds * c.per_cu * (float)(c.bm * c.bn) / c.eff;
+        // blocks that share a CU split its MFMA rate; a grid smaller than one round runs fewer per CU
+        const long conc = std::min<long>(c.per_cu, (nblk + 255) / 256);
+        const float cost = rounds * (float)conc * (float)(c.bm * c.bn) / c.eff;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
+    if (a.act == ACT_GEGLU) best = 0;   // value/gate pairs must sit in one wave's 64-column tile
     switch (best) {
         case 0: return launch_cfg<128, 128, 2, 2>(a, s);
         case 1: return launch_cfg<128, 64, 2, 2>(a, s);

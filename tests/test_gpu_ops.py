@@ -89,9 +89,11 @@ def test_conv(lib, case):
     x0 = nhwc16(x[:, :C0])
     x1 = nhwc16(x[:, C0:]) if C1 else None
     out = torch.empty(B * Ho * Wo * Cout, dtype=torch.half, device='cuda')
-    rc = lib.fgdm_op_conv2d(_p(x0), C0, _p(x1), C1, _p(w.cuda()), _p(bias.cuda()),
-                            _p(rowvec.cuda() if rowvec is not None else None),
-                            _p(nhwc16(resid) if resid is not None else None),
+    # keep every device tensor referenced until the call returns (a temporary's block would be recycled)
+    wd, bd = w.cuda(), bias.cuda()
+    rvd = rowvec.cuda() if rowvec is not None else None
+    rsd = nhwc16(resid) if resid is not None else None
+    rc = lib.fgdm_op_conv2d(_p(x0), C0, _p(x1), C1, _p(wd), _p(bd), _p(rvd), _p(rsd),
                             B, H, W, Cout, ks, stride, up, act, scale, _p(out), _st())
     assert rc == 0
     torch.cuda.synchronize()
@@ -109,7 +111,8 @@ def test_linear_variants(lib):
     a, g = y.chunk(2, dim=-1)
     ref = a * F.gelu(g)
     out = torch.empty(M, N // 2, dtype=torch.half, device='cuda')
-    assert lib.fgdm_op_linear(_p(x.half().cuda()), _p(w.cuda()), _p(b.cuda()), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
+    xd, wd, bd = x.half().cuda(), w.cuda(), b.cuda()
+    assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
     assert relerr(out.float().cpu(), ref) < TOL
     # plain + residual, fp32 output, transposed fp16 output (V^T for attention), ragged rows-per-sample (77)
     N2 = 320
@@ -117,16 +120,18 @@ def test_linear_variants(lib):
     ref = F.linear(x, w2, b2)
     res = h16(rnd((M, N2), 14))
     out = torch.empty(M, N2, dtype=torch.half, device='cuda')
-    assert lib.fgdm_op_linear(_p(x.half().cuda()), _p(w2.cuda()), _p(b2.cuda()), _p(res.half().cuda()), M, K, N2, 0, 0, 0, 0, _p(out), _st()) == 0
+    w2d, b2d, resd = w2.cuda(), b2.cuda(), res.half().cuda()
+    assert lib.fgdm_op_linear(_p(xd), _p(w2d), _p(b2d), _p(resd), M, K, N2, 0, 0, 0, 0, _p(out), _st()) == 0
     assert relerr(out.float().cpu(), ref + res) < TOL
     out32 = torch.empty(M, N2, dtype=torch.float32, device='cuda')
-    assert lib.fgdm_op_linear(_p(x.half().cuda()), _p(w2.cuda()), _p(b2.cuda()), None, M, K, N2, 0, 1, 0, 0, _p(out32), _st()) == 0
+    assert lib.fgdm_op_linear(_p(xd), _p(w2d), _p(b2d), None, M, K, N2, 0, 1, 0, 0, _p(out32), _st()) == 0
     assert relerr(out32.cpu(), ref) < 2e-5 + 0 * TOL     # fp32 store: only accumulation-order error
     for rps, Bt in ((100, 2), (77, 2), (4, 50)):
         Mt = rps * Bt
         ld = (rps + 63) // 64 * 64
         outT = torch.zeros(Bt, N2, ld, dtype=torch.half, device='cuda')
-        assert lib.fgdm_op_linear(_p(x[:Mt].half().cuda()), _p(w2.cuda()), _p(b2.cuda()), None, Mt, K, N2, 0, 3, rps, ld, _p(outT), _st()) == 0
+        xt = x[:Mt].half().cuda()
+        assert lib.fgdm_op_linear(_p(xt), _p(w2d), _p(b2d), None, Mt, K, N2, 0, 3, rps, ld, _p(outT), _st()) == 0
         want = ref[:Mt].view(Bt, rps, N2).permute(0, 2, 1)
         assert relerr(outT[:, :, :rps].float().cpu(), want) < TOL
         assert float(outT[:, :, rps:].abs().max()) == 0.0 if ld > rps else True
@@ -148,7 +153,8 @@ def test_groupnorm(lib, case):
     x0 = nhwc16(x[:, :C0])
     x1 = nhwc16(x[:, C0:]) if C1 else None
     out = torch.empty(B * HW * Cc, dtype=torch.half, device='cuda')
-    assert lib.fgdm_op_groupnorm(_p(x0), C0, _p(x1), C1, B, HW, _p(gamma.cuda()), _p(beta.cuda()), eps, silu, _p(out), _st()) == 0
+    gd, bd = gamma.cuda(), beta.cuda()
+    assert lib.fgdm_op_groupnorm(_p(x0), C0, _p(x1), C1, B, HW, _p(gd), _p(bd), eps, silu, _p(out), _st()) == 0
     assert relerr(from_nhwc(out, B, HW, 1, Cc), ref) < TOL
 
 
@@ -171,7 +177,8 @@ def test_layernorm(lib, C_):
     gamma, beta = 1 + 0.2 * rnd((C_,), 32), 0.1 * rnd((C_,), 33)
     ref = F.layer_norm(x, (C_,), gamma, beta, 1e-5)
     out = torch.empty(rows, C_, dtype=torch.half, device='cuda')
-    assert lib.fgdm_op_layernorm(_p(x.half().cuda()), rows, C_, _p(gamma.cuda()), _p(beta.cuda()), 1e-5, _p(out), _st()) == 0
+    xd, gd, bd = x.half().cuda(), gamma.cuda(), beta.cuda()
+    assert lib.fgdm_op_layernorm(_p(xd), rows, C_, _p(gd), _p(bd), 1e-5, _p(out), _st()) == 0
     assert relerr(out.float().cpu(), ref) < TOL
 
 
@@ -195,8 +202,8 @@ def test_attention(lib, case):
     vt = torch.zeros(B, Cc, Tkp, dtype=torch.half)
     vt[:, :, :Tk] = v.permute(0, 2, 1).half()
     out = torch.empty(B, T, Cc, dtype=torch.half, device='cuda')
-    rc = lib.fgdm_op_attention(_p(q.half().cuda()), Cc, _p(k.half().cuda()), Cc, _p(vt.cuda()), Tkp, _p(out), Cc,
-                               B, Hh, T, Tk, d, _st())
+    qd, kd, vtd = q.half().cuda(), k.half().cuda(), vt.cuda()
+    rc = lib.fgdm_op_attention(_p(qd), Cc, _p(kd), Cc, _p(vtd), Tkp, _p(out), Cc, B, Hh, T, Tk, d, _st())
     assert rc == 0
     assert relerr(out.float().cpu(), ref) < TOL
 
