@@ -24,3 +24,14 @@ def relerr(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def report(name, err, tol):
+    """Record a measured parity error (normwise relative) so it can be quoted; returns err."""
+    line = f'{name}: rel_err={err:.3e} (tol {tol:.1e})'
+    print(line)
+    d = os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity_errors.txt'), 'a') as f:
+            f.write(line + '\n')
+    return err
