@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 images/sec @ 50 DDIM steps, seg-ControlNet + CFG (BASELINE.json configs[2], "C3").
+
+One "step" = one complete 50-step DDIM sampling (eta 0, CFG as one 2B batch) of this rank's 16 prompts through
+SD-v1.5 UNet + one ControlNet, latent 64x64, hint 512x512, inputs already resident in HBM.  Weak scaling:
+every rank samples its own 16 prompts (global x_T / contexts / hints are generated once and sliced), no
+collective inside the loop; frozen weights are generated on rank 0 and broadcast over RCCL before timing.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
+implicit-GEMM family, timed with HIP events on the launch stream inside the timed region) and
+`cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PROMPTS_PER_GPU = 16
+DDIM_STEPS = 50
+CFG_SCALE = 9.0          # reference stage-B default: scripts/txt2img_fgdm_inference.py:292, controlnet/initialize_cn.py:74
+LATENT = 64
+TFLOP_PER_IMAGE = 107.20  # BASELINE.md section 3, config C3 (hint block once per image)
+PEAK_TFLOPS = 2500.0      # dense fp16 MFMA, MI355X_MICROARCH.md
+
+
+def build_engine(rank, world):
+    import torch.distributed as dist
+    from fgdm_amd import synth
+    from fgdm_amd.engine import Engine
+    e = Engine(None, use_adapter=False, n_controlnets=1, device=torch.cuda.current_device())
+    shapes = e.param_shapes()
+    total = sum(int(np.prod(s)) for s in shapes.values())
+    t0 = time.time()
+    if world == 1:
+        for k, s in shapes.items():
+            e.load_tensor(k, synth.make_tensor(k, s))
+    else:
+        # frozen weights: generated on rank 0 only, ONE RCCL broadcast of the flat fp32 buffer over xGMI
+        flat = torch.empty(total, dtype=torch.float32, device='cuda')
+        if rank == 0:
+            off = 0
+            for k, s in shapes.items():
+                n = int(np.prod(s))
+                flat[off:off + n].copy_(torch.from_numpy(synth.make_tensor(k, s).ravel()))
+                off += n
+        dist.broadcast(flat, src=0)
+        off = 0
+        for k, s in shapes.items():
+            n = int(np.prod(s))
+            e.load_tensor(k, flat[off:off + n].view(*s))
+            off += n
+        del flat
+        torch.cuda.empty_cache()
+    e.finalize()
+    return e, total, time.time() - t0
+
+
+def cpu_baseline():
+    """CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the SAME workload:
+    one prompt's CFG pair = 2 x (ControlNet + ControlledUnet) at 64x64 latent, hint 512x512, fp32."""
+    from fgdm_amd import synth
+    from oracle import arch, nn as onn
+    cfg = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1),
+               num_res_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = {}
+    for pre, shapes in (('model.diffusion_model.', arch.unet_param_shapes(cfg, adapter=False)),
+                        ('control_model.', arch.controlnet_param_shapes(cfg))):
+        for k, s in shapes.items():
+            p[pre + k] = torch.from_numpy(synth.make_tensor(pre + k, s))
+    x = torch.from_numpy(synth.latents(1, LATENT, LATENT)).repeat(2, 1, 1, 1)
+    ctx = torch.cat([torch.from_numpy(synth.context(1, seed=44)), torch.from_numpy(synth.context(1, seed=43))])
+    hint = torch.from_numpy(synth.hint(1, 512)).repeat(2, 1, 1, 1)
+    t = torch.full((2,), 981, dtype=torch.long)
+    times = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.time()
+            onn.control_ldm_apply(p, cfg, x, t, ctx, [hint])
+            times.append(time.time() - t0)
+    sec = float(np.mean(times[1:]))            # first call = warm-up
+    return {'value': 1.0 / (DDIM_STEPS * sec), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'2 timed CFG-pair evaluations (B=2: uncond+cond) of ControlNet+UNet @64x64, hint 512^2, '
+                      f'fp32 torch-CPU oracle, {sec:.2f} s each, extrapolated x{DDIM_STEPS} DDIM steps for one image',
+            'sec_per_cfg_pair_eval': sec}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--prompts', type=int, default=PROMPTS_PER_GPU, help='prompts per GPU')
+    ap.add_argument('--ddim-steps', type=int, default=DDIM_STEPS)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus != world and world > 1:
+        print(f'warning: --gpus {a.gpus} != WORLD_SIZE {world}; using WORLD_SIZE', file=sys.stderr)
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from fgdm_amd import synth
+    from oracle import schedule   # host-side schedule tables only (numpy); never on the measured path
+    engine, n_params, load_s = build_engine(rank, world)
+
+    npg = a.prompts
+    N = npg * world
+    sl = slice(rank * npg, (rank + 1) * npg)
+    x_T = torch.from_numpy(synth.latents(N, LATENT, LATENT, seed=42)[sl]).cuda()
+    cond = torch.from_numpy(synth.context(N, seed=43)[sl]).cuda()
+    uncond = torch.from_numpy(synth.context(N, seed=44)[sl]).cuda()
+    hint = torch.from_numpy(synth.hint(N, 512, seed=45)[sl]).cuda()
+    sched = schedule.register_schedule()
+    tab = schedule.ddim_tables(sched['alphas_cumprod'], a.ddim_steps, 0.0)
+
+    def one_step():
+        engine.set_hint(0, hint)          # cached after the first call (t-independent hint block)
+        return engine.sample_ddim(x_T, cond, uncond, CFG_SCALE, tab['timesteps'], tab['alphas'], tab['alphas_prev'],
+                                  tab['sqrt_one_minus_alphas'])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = one_step()
+    barrier()
+    engine.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = engine.profile_end()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all(), 'non-finite latents'
+
+    if rank == 0:
+        images = N * a.steps
+        value = images / dt
+        ig = prof['igemm']
+        achieved = ig['work'] / (ig['ms'] * 1e-3) / 1e12 if ig['ms'] > 0 else 0.0
+        res = {
+            'metric': '512x512 images/sec @ 50 DDIM steps, seg-ControlNet+CFG',
+            'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2] (C3): SD-v1.5 UNet + seg-ControlNet, hint 512x512, '
+                                   f'{npg} prompts per GPU, {a.ddim_steps} DDIM steps eta=0, CFG {CFG_SCALE} '
+                                   'as one 2B batch, latent 4x64x64; synthetic weights/latents/contexts/hints',
+                       'prompts_per_gpu': npg, 'ddim_steps': a.ddim_steps, 'cfg_scale': CFG_SCALE,
+                       'parallelism': f'prompt-shard x{world}, RCCL weight broadcast only'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_TFLOPS, 'traffic': None,
+                         'kernel': 'igemm_kernel<*> (implicit-GEMM conv3x3/conv1x1/linear family)',
+                         'launches': ig['launches'], 'avg_launch_us': ig['ms'] * 1e3 / max(ig['launches'], 1),
+                         'algorithmic_tflop_per_launch': ig['work'] / max(ig['launches'], 1) / 1e12},
+            'kernel_time_ms': {k: round(v['ms'], 3) for k, v in prof.items()},
+            'whole_path_tflops': value * TFLOP_PER_IMAGE * (a.ddim_steps / DDIM_STEPS),
+            'whole_path_mfma_frac': value * TFLOP_PER_IMAGE * (a.ddim_steps / DDIM_STEPS) / (PEAK_TFLOPS * world),
+            'attention_tflops': (prof['attention']['work'] / (prof['attention']['ms'] * 1e-3) / 1e12
+                                 if prof['attention']['ms'] > 0 else 0.0),
+            'norm_GBps': (prof['norm']['work'] / (prof['norm']['ms'] * 1e-3) / 1e9 if prof['norm']['ms'] > 0 else 0.0),
+            'weights': {'params': n_params, 'load_s': round(load_s, 2)},
+            'workspace': engine.workspace_stats(),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

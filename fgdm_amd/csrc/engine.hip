@@ -91,6 +91,7 @@ struct GemmW {              // packed [npad][K] fp16 weight + fp32 bias (packed 
     int N = 0, K = 0;
     bool im2col = false;    // conv3x3 whose Cin is not a multiple of 64: K = roundup64(9 * cin_pad)
     int cin_pad = 0;
+    int k_real = 0;         // un-padded contraction length (algorithmic flop accounting)
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -126,6 +127,38 @@ struct Net {
 
 static int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
+// Built-in kernel timer: when enabled, every launch is bracketed by HIP events recorded on the launch stream
+// (the same stream the kernels run on), so per-kernel-class device time, launch counts and the ALGORITHMIC
+// flops / bytes of exactly those launches can be read back without an external profiler.
+enum ProfClass { PC_IGEMM = 0, PC_ATTN = 1, PC_NORM = 2, PC_ELEM = 3, PC_COUNT = 4 };
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    struct Rec { int cls; size_t e0, e1; };
+    std::vector<Rec> recs;
+    double work[PC_COUNT] = {0, 0, 0, 0};     // flops (igemm, attention) or bytes (norm, elementwise)
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[used++];
+    }
+    void begin(int cls, hipStream_t s, double w) {
+        if (!on) return;
+        hipEvent_t e = get();
+        if (!e) return;
+        (void)hipEventRecord(e, s);
+        recs.push_back({cls, used - 1, 0});
+        work[cls] += w;
+    }
+    void end(hipStream_t s) {
+        if (!on || recs.empty()) return;
+        hipEvent_t e = get();
+        if (!e) return;
+        (void)hipEventRecord(e, s);
+        recs.back().e1 = used - 1;
+    }
+};
+
 }  // namespace
 
 struct fgdm_engine {
@@ -141,6 +174,7 @@ struct fgdm_engine {
     half_t* zero = nullptr;
     std::vector<void*> weight_allocs;
     hipStream_t s = nullptr;      // stream of the call in flight
+    Prof prof;
 
     int fail(int code, const std::string& m) { err = m; return code; }
 
@@ -339,7 +373,7 @@ struct fgdm_engine {
             else for (int k = 0; k < K; ++k) if (kmap[k] >= 0) dst[k] = (half_t)src[kmap[k]];
             bias[pr] = bflat[sr];
         }
-        g.N = N; g.K = K;
+        g.N = N; g.K = K; g.k_real = K_src;
         g.w = upload(w);
         g.bias = upload(bias);
         return (g.w && g.bias) ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed while packing weights");
@@ -510,7 +544,9 @@ struct fgdm_engine {
         const int taps = mode == IG_LINEAR ? 1 : 9;
         if (taps * (a.C0 + a.C1) != a.K) return fail(FGDM_ERR_ARG, "gemm: K mismatch");
         if (!a.out) return fail(FGDM_ERR_NOMEM, "gemm: null output (workspace exhausted?)");
+        prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real);
         const int rc = igemm_launch(a, s);
+        prof.end(s);
         return rc == FGDM_OK ? rc : fail(rc, "igemm launch failed");
     }
     // conv3x3 (stride 1/2, or on the nearest-2x upsampled input) -> new tensor
@@ -524,7 +560,9 @@ struct fgdm_engine {
         if (up || x1 || x.C != w.cin_pad) return fail(FGDM_ERR_ARG, "im2col conv path: unsupported combination");
         Tensor A = talloc(1, 1, x.B * Ho * Wo, w.K);
         if (!A.p) return fail(FGDM_ERR_NOMEM, "workspace (im2col)");
+        prof.begin(PC_ELEM, s, 2.0 * (double)A.numel() + 2.0 * (double)x.numel());
         int rc = im2col3x3(x.p, A.p, x.B, x.H, x.W, x.C, stride, w.K, s);
+        prof.end(s);
         if (rc != FGDM_OK) return fail(rc, "im2col failed");
         Tensor Av = A; Av.B = x.B; Av.H = Ho; Av.W = Wo; Av.C = w.K;
         if (!e.rps) e.rps = Ho * Wo;
@@ -541,15 +579,19 @@ struct fgdm_engine {
         *out = talloc(x.B, x.H, x.W, C);
         float* ws = (float*)arena.alloc(groupnorm_ws_floats(x.B, x.H * x.W) * sizeof(float));
         if (!out->p || !ws) return fail(FGDM_ERR_NOMEM, "workspace");
+        prof.begin(PC_NORM, s, 4.0 * (double)out->numel());   // algorithmic: read once + write once, fp16
         const int rc = groupnorm_launch(x.p, x.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, x.B, x.H * x.W, n.g, n.b, eps,
                                         silu ? 1 : 0, out->p, ws, s);
+        prof.end(s);
         arena.release(ws);
         return rc == FGDM_OK ? rc : fail(rc, "groupnorm launch failed");
     }
     int lnorm(const NormW& n, const Tensor& x, Tensor* out) {
         *out = talloc(x.B, x.H, x.W, x.C);
         if (!out->p) return fail(FGDM_ERR_NOMEM, "workspace");
+        prof.begin(PC_NORM, s, 4.0 * (double)out->numel());
         const int rc = layernorm_launch(x.p, x.rows(), x.C, n.g, n.b, 1e-5f, out->p, s);
+        prof.end(s);
         return rc == FGDM_OK ? rc : fail(rc, "layernorm launch failed");
     }
 
@@ -596,7 +638,9 @@ struct fgdm_engine {
         tfree(n);
         a = talloc(B, x.H, x.W, C);
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        { int rc = attention_launch(qk.p, 2 * C, qk.p + C, 2 * C, vt.p, Tp, a.p, C, B, l.heads, T, T, d, s);
+        { prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)T * C);
+          int rc = attention_launch(qk.p, 2 * C, qk.p + C, 2 * C, vt.p, Tp, a.p, C, B, l.heads, T, T, d, s);
+          prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed (unsupported head dim?)"); }
         tfree(qk); tfree(vt);
         { Epi e; e.resid = h.p; e.ld_res = C; CHK(linear(l.o1, a, e, &h2)); }
@@ -613,7 +657,9 @@ struct fgdm_engine {
         { Epi e; e.out_kind = OUT_F16_T; e.out = v2t.p; e.ld_out = Tkp; e.rps = Tk; CHK(linear(l.v2, ctx16, e, nullptr)); }
         a = talloc(B, x.H, x.W, C);
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        { int rc = attention_launch(q2.p, C, k2.p, C, v2t.p, Tkp, a.p, C, B, l.heads, T, Tk, d, s);
+        { prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)Tk * C);
+          int rc = attention_launch(q2.p, C, k2.p, C, v2t.p, Tkp, a.p, C, B, l.heads, T, Tk, d, s);
+          prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed"); }
         tfree(q2); tfree(k2); tfree(v2t);
         { Epi e; e.resid = h2.p; e.ld_res = C; CHK(linear(l.o2, a, e, &h)); }
@@ -921,6 +967,7 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
 
 void fgdm_destroy(fgdm_engine* e) {
     if (!e) return;
+    for (hipEvent_t ev : e->prof.pool) (void)hipEventDestroy(ev);
     for (void* p : e->weight_allocs) (void)hipFree(p);
     if (e->zero) (void)hipFree(e->zero);
     for (auto& n : e->cns) if (n.guided.p) (void)hipFree(n.guided.p);
@@ -988,6 +1035,40 @@ int fgdm_finalize_weights(fgdm_engine* e) {
     if (rc != FGDM_OK) return rc;
     for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }
     e->finalized = true;
+    return FGDM_OK;
+}
+
+int fgdm_profile_begin(fgdm_engine* e) {
+    if (!e) return FGDM_ERR_ARG;
+    e->prof.on = true;
+    e->prof.used = 0;
+    e->prof.recs.clear();
+    for (int c = 0; c < PC_COUNT; ++c) e->prof.work[c] = 0;
+    return FGDM_OK;
+}
+// out[class][3] = {device milliseconds, launches, algorithmic work (flops for classes 0/1, bytes for 2/3)};
+// classes: 0 implicit-GEMM (conv / linear), 1 attention, 2 GroupNorm + LayerNorm, 3 im2col.  Synchronises the device.
+int fgdm_profile_end(fgdm_engine* e, double* out) {
+    if (!e || !out) return FGDM_ERR_ARG;
+    e->prof.on = false;
+    if (hipDeviceSynchronize() != hipSuccess) return e->fail(FGDM_ERR_HIP, "hipDeviceSynchronize failed");
+    for (int c = 0; c < PC_COUNT * 3; ++c) out[c] = 0;
+    for (auto& r : e->prof.recs) {
+        if (!r.e1) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->prof.pool[r.e0], e->prof.pool[r.e1]) != hipSuccess) continue;
+        out[r.cls * 3 + 0] += ms;
+        out[r.cls * 3 + 1] += 1;
+    }
+    for (int c = 0; c < PC_COUNT; ++c) out[c * 3 + 2] = e->prof.work[c];
+    return FGDM_OK;
+}
+int fgdm_workspace_stats(fgdm_engine* e, int64_t* peak_bytes, int64_t* reserved_bytes) {
+    if (!e || !peak_bytes || !reserved_bytes) return FGDM_ERR_ARG;
+    *peak_bytes = (int64_t)e->arena.peak;
+    size_t r = 0;
+    for (auto& sl : e->arena.slabs) for (auto& b : sl) r += b.sz;
+    *reserved_bytes = (int64_t)r;
     return FGDM_OK;
 }
 

@@ -192,6 +192,24 @@ class Engine:
             off += n
         return outs
 
+    # ------------------------------------------------------------------ built-in kernel timer
+    PROFILE_CLASSES = ('igemm', 'attention', 'norm', 'im2col')
+
+    def profile_begin(self):
+        self._check(self.lib.fgdm_profile_begin(self.h), 'fgdm_profile_begin')
+
+    def profile_end(self):
+        """{class: dict(ms, launches, work)}; work = algorithmic flops (igemm, attention) or bytes (norm, im2col)."""
+        buf = (C.c_double * 12)()
+        self._check(self.lib.fgdm_profile_end(self.h, buf), 'fgdm_profile_end')
+        return {n: dict(ms=buf[3 * i], launches=int(buf[3 * i + 1]), work=buf[3 * i + 2])
+                for i, n in enumerate(self.PROFILE_CLASSES)}
+
+    def workspace_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.fgdm_workspace_stats(self.h, C.byref(a), C.byref(b)), 'fgdm_workspace_stats')
+        return dict(peak_bytes=a.value, reserved_bytes=b.value)
+
     def control_shapes(self, B, H, W):
         c = self.config
         mc = c.model_channels

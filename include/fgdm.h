@@ -105,6 +105,15 @@ int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* u
                      const float* sqrt_one_minus_alphas, const float* control_scales, int B, int H, int W,
                      int flags, void* stream);
 
+/* Built-in kernel timer (no reference counterpart: the reference only prints wall-clock, scripts/txt2img.py:381-396).
+ * Between begin and end every kernel launch is bracketed by HIP events on the launch stream.
+ * out: 4 classes x {device ms, launches, algorithmic work}; classes: 0 implicit GEMM (flops), 1 attention (flops),
+ * 2 GroupNorm+LayerNorm (bytes), 3 im2col (bytes).  fgdm_profile_end synchronises the device. */
+int fgdm_profile_begin(fgdm_engine* e);
+int fgdm_profile_end(fgdm_engine* e, double* out);
+/* Activation workspace: peak bytes in use during the last calls, and bytes reserved from HBM. */
+int fgdm_workspace_stats(fgdm_engine* e, int64_t* peak_bytes, int64_t* reserved_bytes);
+
 /* Per-kernel entry points used by the parity tests (tests/test_gpu_ops.py); weights given in the reference's
  * native layouts (fp32, [Cout,Cin,kh,kw] / [N,K]) and packed on the fly.  Activations fp16 NHWC. */
 int fgdm_op_conv2d(const void* x0, int C0, const void* x1, int C1, const float* w, const float* bias,
