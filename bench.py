@@ -30,36 +30,20 @@ TFLOP_PER_IMAGE = 107.20  # BASELINE.md section 3, config C3 (hint block once pe
 PEAK_TFLOPS = 2500.0      # dense fp16 MFMA, MI355X_MICROARCH.md
 
 
-def build_engine(rank, world):
-    import torch.distributed as dist
-    from fgdm_amd import synth
-    from fgdm_amd.engine import Engine
-    e = Engine(None, use_adapter=False, n_controlnets=1, device=torch.cuda.current_device())
-    shapes = e.param_shapes()
-    total = sum(int(np.prod(s)) for s in shapes.values())
+def build_model(rank, world):
+    """ControlLDM mirror (reference API) over the HIP engine; frozen weights are generated on rank 0 only and
+    shipped with ONE RCCL broadcast of a flat fp32 buffer (fgdm_amd/dist.py)."""
+    from fgdm_amd import dist as fd, models, synth
     t0 = time.time()
-    if world == 1:
-        for k, s in shapes.items():
-            e.load_tensor(k, synth.make_tensor(k, s))
-    else:
-        # frozen weights: generated on rank 0 only, ONE RCCL broadcast of the flat fp32 buffer over xGMI
-        flat = torch.empty(total, dtype=torch.float32, device='cuda')
-        if rank == 0:
-            off = 0
-            for k, s in shapes.items():
-                n = int(np.prod(s))
-                flat[off:off + n].copy_(torch.from_numpy(synth.make_tensor(k, s).ravel()))
-                off += n
-        dist.broadcast(flat, src=0)
-        off = 0
-        for k, s in shapes.items():
-            n = int(np.prod(s))
-            e.load_tensor(k, flat[off:off + n].view(*s))
-            off += n
-        del flat
-        torch.cuda.empty_cache()
-    e.finalize()
-    return e, total, time.time() - t0
+    model = models.ControlLDM(None, n_controlnets=1, device=torch.cuda.current_device())
+    shapes = model.engine.param_shapes()
+    sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, 'cuda')
+    missing, _ = model.load_state_dict(sd, strict=True)
+    assert not missing
+    n_params = flat.numel()
+    del sd, flat
+    torch.cuda.empty_cache()
+    return model, n_params, time.time() - t0
 
 
 def cpu_baseline():
@@ -115,8 +99,10 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     from fgdm_amd import synth
-    from oracle import schedule   # host-side schedule tables only (numpy); never on the measured path
-    engine, n_params, load_s = build_engine(rank, world)
+    from fgdm_amd import samplers
+    model, n_params, load_s = build_model(rank, world)
+    engine = model.engine
+    sampler = samplers.ControlDDIMSampler(model)       # drop-in for controlnet/cldm/ddim_hacked.py:DDIMSampler
 
     npg = a.prompts
     N = npg * world
@@ -125,13 +111,14 @@ def main():
     cond = torch.from_numpy(synth.context(N, seed=43)[sl]).cuda()
     uncond = torch.from_numpy(synth.context(N, seed=44)[sl]).cuda()
     hint = torch.from_numpy(synth.hint(N, 512, seed=45)[sl]).cuda()
-    sched = schedule.register_schedule()
-    tab = schedule.ddim_tables(sched['alphas_cumprod'], a.ddim_steps, 0.0)
+    # the call the reference makes at controlnet/initialize_cn.py:86-96 (guess_mode=False: control on both branches)
+    c_cond = {'c_concat': [hint], 'c_crossattn': [cond]}
+    c_uncond = {'c_concat': [hint], 'c_crossattn': [uncond]}
 
     def one_step():
-        engine.set_hint(0, hint)          # cached after the first call (t-independent hint block)
-        return engine.sample_ddim(x_T, cond, uncond, CFG_SCALE, tab['timesteps'], tab['alphas'], tab['alphas_prev'],
-                                  tab['sqrt_one_minus_alphas'])
+        out, _ = sampler.sample(a.ddim_steps, npg, (4, LATENT, LATENT), c_cond, verbose=False, eta=0.0, x_T=x_T,
+                                unconditional_guidance_scale=CFG_SCALE, unconditional_conditioning=c_uncond)
+        return out
 
     def barrier():
         if world > 1:
@@ -166,7 +153,8 @@ def main():
             'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2] (C3): SD-v1.5 UNet + seg-ControlNet, hint 512x512, '
                                    f'{npg} prompts per GPU, {a.ddim_steps} DDIM steps eta=0, CFG {CFG_SCALE} '
-                                   'as one 2B batch, latent 4x64x64; synthetic weights/latents/contexts/hints',
+                                   'as one 2B batch, latent 4x64x64, through the drop-in ControlLDM.apply_model + '
+                                   'DDIMSampler.sample API; synthetic weights/latents/contexts/hints',
                        'prompts_per_gpu': npg, 'ddim_steps': a.ddim_steps, 'cfg_scale': CFG_SCALE,
                        'parallelism': f'prompt-shard x{world}, RCCL weight broadcast only'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -49,6 +49,7 @@ SIGNATURES = {
     'fgdm_ddim_step': (_i, [_p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i64, _p]),
     'fgdm_plms_combine': (_i, [_p, _p, _p, _p, _i, _p, _i64, _p]),
     'fgdm_axpby': (_i, [_p, _f, _p, _f, _p, _i64, _p]),
+    'fgdm_mask_blend': (_i, [_p, _p, _p, _p, _i64, _p]),
     'fgdm_ancestral_step': (_i, [_p, _p, _f, _f, _f, _f, _f, _p, _p, _i64, _p]),
     'fgdm_sample_ddim': (_i, [_p, _p, _p, _p, _f, _i, C.POINTER(_i64), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
                               _p, _i, _i, _i, _i, _p]),

@@ -75,6 +75,7 @@ int ddim_step(const float* x, const float* e_cond, const float* e_uncond, float 
 int plms_combine(const float* e_t, const float* e1, const float* e2, const float* e3, int order,
                  float* e_prime, size_t n, hipStream_t s);
 int axpby(const float* a, float ca, const float* b, float cb, float* y, size_t n, hipStream_t s);
+int mask_blend(const float* a, const float* b, const float* m, float* y, size_t n, hipStream_t s);
 int ancestral_step(const float* x, const float* eps, float sqrt_recip, float sqrt_recipm1, float coef1, float coef2,
                    float std, const float* noise, float* out, size_t n, hipStream_t s);
 

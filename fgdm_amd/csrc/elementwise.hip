@@ -206,6 +206,16 @@ int axpby(const float* a, float ca, const float* b, float cb, float* y, size_t n
     return LAUNCH_OK();
 }
 
+// inpainting blend img_orig * mask + (1 - mask) * img (ddim.py:151-154, ddpm.py:1419-1421); mask pre-expanded
+__global__ void k_mask_blend(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ m,
+                             float* __restrict__ y, size_t n) {
+    EW_LOOP(i, n) y[i] = a[i] * m[i] + (1.0f - m[i]) * b[i];
+}
+int mask_blend(const float* a, const float* b, const float* m, float* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_blend, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, b, m, y, n);
+    return LAUNCH_OK();
+}
+
 // ancestral step (ddpm.py:284-297, 1318-1323): x0 = c_r x - c_rm1 eps; mean = c1 x0 + c2 x; out = mean + std * noise
 __global__ void k_ancestral(const float* __restrict__ x, const float* __restrict__ eps, float cr, float crm1, float c1,
                             float c2, float std, const float* __restrict__ noise, float* __restrict__ out, size_t n) {

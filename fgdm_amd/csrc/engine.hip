@@ -1116,6 +1116,10 @@ int fgdm_axpby(const float* a, float ca, const float* b, float cb, float* y, int
     if (!a || !y || n <= 0) return FGDM_ERR_ARG;
     return axpby(a, ca, b, cb, y, (size_t)n, as_stream(stream));
 }
+int fgdm_mask_blend(const float* a, const float* b, const float* mask, float* y, int64_t n, void* stream) {
+    if (!a || !b || !mask || !y || n <= 0) return FGDM_ERR_ARG;
+    return mask_blend(a, b, mask, y, (size_t)n, as_stream(stream));
+}
 int fgdm_ancestral_step(const float* x, const float* eps, float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1,
                         float coef2, float std, const float* noise, float* out, int64_t n, void* stream) {
     if (!x || !eps || !out || n <= 0) return FGDM_ERR_ARG;

@@ -294,6 +294,16 @@ def axpby(a, ca, b, cb):
     return y
 
 
+def mask_blend(a, b, mask):
+    """a*mask + (1-mask)*b with a full-shape mask."""
+    lib = _lib.load()
+    y = torch.empty_like(a)
+    rc = lib.fgdm_mask_blend(_ptr(a), _ptr(b), _ptr(mask), _ptr(y), a.numel(), _stream())
+    if rc != 0:
+        raise RuntimeError(f'fgdm_mask_blend failed: {rc}')
+    return y
+
+
 def ancestral_step(x, eps, sqrt_recip, sqrt_recipm1, coef1, coef2, std, noise=None):
     lib = _lib.load()
     out = torch.empty_like(x)

@@ -92,6 +92,9 @@ int fgdm_plms_combine(const float* e_t, const float* e1, const float* e2, const 
                       float* e_prime, int64_t n, void* stream);
 /* y = ca*a + cb*b (b may be NULL): the Heun-like first PLMS step (plms.py:219-223) and mask blends (ddim.py:151-154) */
 int fgdm_axpby(const float* a, float ca, const float* b, float cb, float* y, int64_t n, void* stream);
+/* y = a*mask + (1-mask)*b, mask already expanded to n elements: the inpainting blend of ddim.py:151-154 /
+ * ldm/models/diffusion/ddpm.py:1419-1421. */
+int fgdm_mask_blend(const float* a, const float* b, const float* mask, float* y, int64_t n, void* stream);
 /* p_sample / p_mean_variance / q_posterior (ldm/models/diffusion/ddpm.py:284-297,1260-1323) for one timestep. */
 int fgdm_ancestral_step(const float* x, const float* eps, float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1,
                         float coef2, float std, const float* noise, float* out, int64_t n, void* stream);
