@@ -20,6 +20,10 @@ from . import _lib, schedule
 from . import engine as _k
 
 
+def _randn(shape, device):
+    return torch.randn(shape, device=device)
+
+
 class _Buffers:
     """schedule tables as float32 torch tensors on the model's device (attribute names of register_schedule)."""
 
@@ -148,7 +152,7 @@ class LatentDiffusion(_Buffers):
         eps = self.apply_model(x, t, c, **kwargs)
         h = self._host
         if noise is None:
-            noise = torch.randn((1, *x.shape[1:]) if repeat_noise else x.shape, device=x.device)
+            noise = _randn((1, *x.shape[1:]) if repeat_noise else x.shape, x.device)
             noise = noise.expand_as(x).contiguous()
         std = 0.0 if ti == 0 else float(np.exp(0.5 * h['posterior_log_variance_clipped'][ti])) * temperature
         out = _k.ancestral_step(x.contiguous(), eps, h['sqrt_recip_alphas_cumprod'][ti],
@@ -165,7 +169,7 @@ class LatentDiffusion(_Buffers):
             raise NotImplementedError('quantize_denoised needs a VQ first stage')
         log_every_t = log_every_t or self.log_every_t
         b = shape[0]
-        img = torch.randn(shape, device=self.device) if x_T is None else x_T.to(self.device, torch.float32)
+        img = _randn(shape, self.device) if x_T is None else x_T.to(self.device, torch.float32)
         inter = [img]
         timesteps = self.num_timesteps if timesteps is None else timesteps
         if start_T is not None:

@@ -19,6 +19,7 @@ STOL = 2e-5     # fp32 on both sides; device sin/FMA contraction differ from the
 def cpu_noise(monkeypatch):
     """draw sampler noise from the CPU generator (as the reference run that produced the goldens did)"""
     monkeypatch.setattr(samplers, '_randn', lambda shape, device: torch.randn(shape).to(device))
+    monkeypatch.setattr(models, '_randn', lambda shape, device: torch.randn(shape).to(device))
     monkeypatch.setattr(torch, 'randn_like', lambda x, **k: torch.randn(x.shape).to(x.device))
 
 

@@ -37,6 +37,7 @@ def stubs(monkeypatch):
     monkeypatch.setattr(samplers, '_k', kernel_stubs)
     monkeypatch.setattr(models, '_k', kernel_stubs)
     monkeypatch.setattr(samplers, '_randn', lambda shape, device: torch.randn(shape))
+    monkeypatch.setattr(models, '_randn', lambda shape, device: torch.randn(shape))
 
 
 def test_make_schedule_attributes_match_reference(stubs):
