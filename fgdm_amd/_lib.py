@@ -58,6 +58,8 @@ SIGNATURES = {
     'fgdm_workspace_stats': (_i, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
     'fgdm_op_conv2d': (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
     'fgdm_op_linear': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    'fgdm_debug_force_igemm_cfg': (_i, [_i]),
+    'fgdm_bench_igemm': (_i, [_i] * 13 + [C.POINTER(_f)]),
     'fgdm_op_groupnorm': (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _f, _i, _p, _p]),
     'fgdm_op_layernorm': (_i, [_p, _i, _i, _p, _p, _f, _p, _p]),
     'fgdm_op_attention': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -41,9 +41,12 @@ struct IgemmArgs {
     int rv_stride;
     int rows_per_sample;   // Ho*Wo (LINEAR: tokens per sample) -> sample index b = m / rows_per_sample
     float scale;           // (acc + bias + rowvec -> act) * scale + resid
+    int force_cfg;         // 0 = pick automatically; k > 0 = tile configuration k-1 (tuning / benchmarks)
 };
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
+void igemm_set_force_cfg(int cfg);   // process-wide override of the tile choice (0 = automatic)
+int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s);   // pipelined big-tile kernel (igemm2.hip)
 size_t igemm_npad(int n);   // rows the packed weight must provide
 
 // ---------------------------------------------------------------- norms

@@ -12,7 +12,9 @@
 #include "../../include/fgdm.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -135,19 +137,21 @@ struct Prof {
     bool on = false;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
-    struct Rec { int cls; size_t e0, e1; };
+    struct Rec { int cls; size_t e0, e1; double w; char tag[56]; };
     std::vector<Rec> recs;
     double work[PC_COUNT] = {0, 0, 0, 0};     // flops (igemm, attention) or bytes (norm, elementwise)
     hipEvent_t get() {
         if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
         return pool[used++];
     }
-    void begin(int cls, hipStream_t s, double w) {
+    void begin(int cls, hipStream_t s, double w, const char* tag = "") {
         if (!on) return;
         hipEvent_t e = get();
         if (!e) return;
         (void)hipEventRecord(e, s);
-        recs.push_back({cls, used - 1, 0});
+        Rec r{cls, used - 1, 0, w, {0}};
+        snprintf(r.tag, sizeof(r.tag), "%s", tag);
+        recs.push_back(r);
         work[cls] += w;
     }
     void end(hipStream_t s) {
@@ -544,7 +548,9 @@ struct fgdm_engine {
         const int taps = mode == IG_LINEAR ? 1 : 9;
         if (taps * (a.C0 + a.C1) != a.K) return fail(FGDM_ERR_ARG, "gemm: K mismatch");
         if (!a.out) return fail(FGDM_ERR_NOMEM, "gemm: null output (workspace exhausted?)");
-        prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real);
+        char tag[56] = "";
+        if (prof.on) snprintf(tag, sizeof(tag), "igemm M%d N%d K%d mode%d act%d out%d", a.M, a.N, a.K, a.mode, a.act, a.out_kind);
+        prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real, tag);
         const int rc = igemm_launch(a, s);
         prof.end(s);
         return rc == FGDM_OK ? rc : fail(rc, "igemm launch failed");
@@ -579,7 +585,9 @@ struct fgdm_engine {
         *out = talloc(x.B, x.H, x.W, C);
         float* ws = (float*)arena.alloc(groupnorm_ws_floats(x.B, x.H * x.W) * sizeof(float));
         if (!out->p || !ws) return fail(FGDM_ERR_NOMEM, "workspace");
-        prof.begin(PC_NORM, s, 4.0 * (double)out->numel());   // algorithmic: read once + write once, fp16
+        char tag[56] = "";
+        if (prof.on) snprintf(tag, sizeof(tag), "groupnorm B%d HW%d C%d", x.B, x.H * x.W, C);
+        prof.begin(PC_NORM, s, 4.0 * (double)out->numel(), tag);   // algorithmic: read once + write once, fp16
         const int rc = groupnorm_launch(x.p, x.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, x.B, x.H * x.W, n.g, n.b, eps,
                                         silu ? 1 : 0, out->p, ws, s);
         prof.end(s);
@@ -589,7 +597,9 @@ struct fgdm_engine {
     int lnorm(const NormW& n, const Tensor& x, Tensor* out) {
         *out = talloc(x.B, x.H, x.W, x.C);
         if (!out->p) return fail(FGDM_ERR_NOMEM, "workspace");
-        prof.begin(PC_NORM, s, 4.0 * (double)out->numel());
+        char tag[56] = "";
+        if (prof.on) snprintf(tag, sizeof(tag), "layernorm rows%d C%d", x.rows(), x.C);
+        prof.begin(PC_NORM, s, 4.0 * (double)out->numel(), tag);
         const int rc = layernorm_launch(x.p, x.rows(), x.C, n.g, n.b, 1e-5f, out->p, s);
         prof.end(s);
         return rc == FGDM_OK ? rc : fail(rc, "layernorm launch failed");
@@ -638,7 +648,8 @@ struct fgdm_engine {
         tfree(n);
         a = talloc(B, x.H, x.W, C);
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        { prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)T * C);
+        { char tag[56]; snprintf(tag, sizeof(tag), "attn B%d T%d Tk%d d%d", B, T, T, d);
+          prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)T * C, tag);
           int rc = attention_launch(qk.p, 2 * C, qk.p + C, 2 * C, vt.p, Tp, a.p, C, B, l.heads, T, T, d, s);
           prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed (unsupported head dim?)"); }
@@ -657,7 +668,8 @@ struct fgdm_engine {
         { Epi e; e.out_kind = OUT_F16_T; e.out = v2t.p; e.ld_out = Tkp; e.rps = Tk; CHK(linear(l.v2, ctx16, e, nullptr)); }
         a = talloc(B, x.H, x.W, C);
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        { prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)Tk * C);
+        { char tag[56]; snprintf(tag, sizeof(tag), "attn B%d T%d Tk%d d%d", B, T, Tk, d);
+          prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)Tk * C, tag);
           int rc = attention_launch(q2.p, C, k2.p, C, v2t.p, Tkp, a.p, C, B, l.heads, T, Tk, d, s);
           prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed"); }
@@ -1061,6 +1073,21 @@ int fgdm_profile_end(fgdm_engine* e, double* out) {
         out[r.cls * 3 + 1] += 1;
     }
     for (int c = 0; c < PC_COUNT; ++c) out[c * 3 + 2] = e->prof.work[c];
+    // optional per-shape dump: FGDM_PROF_DUMP=<path>  ->  "tag <tab> launches <tab> total_ms <tab> work"
+    if (const char* path = getenv("FGDM_PROF_DUMP")) {
+        std::map<std::string, std::array<double, 3>> agg;
+        for (auto& r : e->prof.recs) {
+            if (!r.e1) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e->prof.pool[r.e0], e->prof.pool[r.e1]) != hipSuccess) continue;
+            auto& a = agg[r.tag];
+            a[0] += 1; a[1] += ms; a[2] += r.w;
+        }
+        if (FILE* f = fopen(path, "w")) {
+            for (auto& kv : agg) fprintf(f, "%s\t%.0f\t%.4f\t%.6g\n", kv.first.c_str(), kv.second[0], kv.second[1], kv.second[2]);
+            fclose(f);
+        }
+    }
     return FGDM_OK;
 }
 int fgdm_workspace_stats(fgdm_engine* e, int64_t* peak_bytes, int64_t* reserved_bytes) {
@@ -1237,6 +1264,57 @@ int fgdm_op_linear(const void* x, const float* w, const float* bias, const void*
     a.rows_per_sample = rows_per_sample ? rows_per_sample : M; a.scale = 1.f;
     const int rc = igemm_launch(a, s);
     (void)hipStreamSynchronize(s);
+    return rc;
+}
+
+int fgdm_debug_force_igemm_cfg(int cfg) { igemm_set_force_cfg(cfg); return FGDM_OK; }
+
+// Micro-benchmark of one conv / linear shape on random data: average device ms over `iters` launches.
+int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample, int act,
+                     int use_resid, int cfg, int iters, float* avg_ms) {
+    if (!avg_ms || iters <= 0 || (ksize != 1 && ksize != 3)) return FGDM_ERR_ARG;
+    const int Cin = C0 + C1, taps = ksize * ksize, K = taps * Cin;
+    if (Cin & 63) return FGDM_ERR_ARG;
+    int Ho = H, Wo = W, mode = ksize == 3 ? IG_CONV3 : IG_LINEAR;
+    if (ksize == 3 && upsample) { Ho = 2 * H; Wo = 2 * W; mode = IG_CONV3_UP2; }
+    else if (ksize == 3 && stride == 2) { Ho = (H - 1) / 2 + 1; Wo = (W - 1) / 2 + 1; mode = IG_CONV3_S2; }
+    const size_t M = (size_t)B * Ho * Wo, nin = (size_t)B * H * W;
+    const size_t npad = igemm_npad(Cout);
+    const int nout = act == ACT_GEGLU ? Cout / 2 : Cout;
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 9) & 0xffff) / 32768.0f - 1.0f; };
+    std::vector<half_t> hx0(nin * C0), hx1(nin * (size_t)std::max(C1, 1)), hw(npad * (size_t)K), hr(M * nout);
+    std::vector<float> hb(npad);
+    for (auto& v : hx0) v = (half_t)rnd();
+    for (auto& v : hx1) v = (half_t)rnd();
+    const float ws = 1.0f / sqrtf((float)K);
+    for (auto& v : hw) v = (half_t)(rnd() * ws);
+    for (auto& v : hr) v = (half_t)rnd();
+    for (auto& v : hb) v = rnd() * 0.1f;
+    TmpDev tmp;
+    half_t* out = nullptr;
+    if (hipMalloc(&out, M * nout * sizeof(half_t)) != hipSuccess) return FGDM_ERR_NOMEM;
+    tmp.ptrs.push_back(out);
+    IgemmArgs a{};
+    a.A0 = tmp.up(hx0); a.C0 = C0; a.A1 = C1 ? tmp.up(hx1) : nullptr; a.C1 = C1;
+    a.Wt = tmp.up(hw); a.bias = tmp.up(hb); a.zero = g_zero_page();
+    a.resid = use_resid ? tmp.up(hr) : nullptr; a.ld_res = nout;
+    if (!a.A0 || !a.Wt || !a.bias || !a.zero) return FGDM_ERR_NOMEM;
+    a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.mode = mode;
+    a.M = (int)M; a.N = Cout; a.K = K; a.act = act; a.out_kind = OUT_F16; a.out = out; a.ld_out = nout;
+    a.rows_per_sample = Ho * Wo; a.scale = 1.f; a.force_cfg = cfg;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = FGDM_OK;
+    for (int i = 0; i < 3 && rc == FGDM_OK; ++i) rc = igemm_launch(a, nullptr);
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && rc == FGDM_OK; ++i) rc = igemm_launch(a, nullptr);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
 }
 

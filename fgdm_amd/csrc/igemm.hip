@@ -175,6 +175,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
             float gbias = 0.f;
             if (geglu) gbias = a.bias ? a.bias[pcol + 32] : 0.f;
             const int ocol = geglu ? ((pcol >> 6) << 5) + lrow : pcol;
+            // per-sample emb values for this lane's 16 rows: all loads issued before any store (stores to `out`
+            // may alias for the compiler and would otherwise serialise each load behind the previous store)
+            float rvv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rvv[r] = (a.rowvec && row < a.M) ? a.rowvec[(size_t)(row / rps) * a.rv_stride + pcol] : 0.f;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int row0 = m0 + wm * TM + i * 32 + 8 * g + 4 * lh;
@@ -182,8 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int row = row0 + e;
-                    float x = acc[i][j][g * 4 + e] + bias;
-                    if (a.rowvec && row < a.M) x += a.rowvec[(size_t)(row / rps) * a.rv_stride + pcol];
+                    float x = acc[i][j][g * 4 + e] + bias + rvv[g * 4 + e];
                     if (a.act == ACT_SILU) x = silu_f(x);
                     else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
                     else if (geglu) {
@@ -254,10 +261,28 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
-// Pick the tile shape with the lowest modelled time: waves-of-blocks x tile area / relative efficiency.
+// Tile selection.  Large layers whose N is a multiple of 320 (every SD-v1 width) or, for GEGLU, of 256 go to the
+// pipelined big-tile kernel (igemm2.hip); everything else (N = 4 output conv, hint block, tiny M) uses the
+// 2-stage kernel above with the tile of lowest modelled time.
+static int g_force_cfg = 0;
+void igemm_set_force_cfg(int cfg) { g_force_cfg = cfg; }
+
 int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 63) || (a.C0 & 63) || (a.C1 & 63)) return FGDM_ERR_ARG;
     if (a.act == ACT_GEGLU && (a.N & 63)) return FGDM_ERR_ARG;
+    int force = a.force_cfg ? a.force_cfg : g_force_cfg;
+    if (force == 0) {
+        const bool geglu = a.act == ACT_GEGLU;
+        if (!geglu && a.N % 320 == 0) {
+            const long b256 = (long)((a.M + 255) / 256) * (a.N / 320);
+            const long b128 = (long)((a.M + 127) / 128) * (a.N / 320);
+            if (b256 >= 192) force = 4;
+            else if (b128 >= 96) force = 6;
+        } else if (geglu && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= 128) {
+            force = 5;
+        }
+    }
+    if (force >= 4) return igemm2_launch(a, force - 4, s);
     struct Cfg { int bm, bn; float eff; int per_cu; };
     static const Cfg cfgs[] = {{128, 128, 1.00f, 2}, {128, 64, 0.80f, 3}, {64, 64, 0.62f, 4}};
     int best = 0;
@@ -267,12 +292,14 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
         const long nblk = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
         const long slots = 256L * c.per_cu;
         const float rounds = (float)((nblk + slots - 1) / slots);
-        // blocks that share a CU split its MFMA rate; a grid smaller than one round runs fewer per CU
         const long conc = std::min<long>(c.per_cu, (nblk + 255) / 256);
         const float cost = rounds * (float)conc * (float)(c.bm * c.bn) / c.eff;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
+    // a grid that cannot fill the chip with 128x128 tiles runs faster on 64x64 tiles (measured: M = 2048 layers)
+    if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 256) best = 2;
     if (a.act == ACT_GEGLU) best = 0;   // value/gate pairs must sit in one wave's 64-column tile
+    if (force >= 1 && force <= 3) best = force - 1;
     switch (best) {
         case 0: return launch_cfg<128, 128, 2, 2>(a, s);
         case 1: return launch_cfg<128, 64, 2, 2>(a, s);

@@ -1,0 +1,336 @@
+// Pipelined implicit-GEMM kernel for the large layers (second-generation of igemm.hip; same IgemmArgs contract).
+//
+// What changed against igemm_kernel, and why (measured on MI355X, profiles/r01_*):
+//   * one 512-thread workgroup per CU owns a 256x320 / 256x256 / 128x320 output tile (N = 320 k for every SD
+//     layer, so no column waste) -> 2x the flops per byte staged into LDS;
+//   * BK = 32, FOUR-stage LDS ring filled by global_load_lds_dwordx4, waited with a COUNTED s_waitcnt vmcnt so
+//     two stages stay in flight across the (single, raw) s_barrier of each K-step -- the old kernel drained to
+//     vmcnt(0) every step and ran latency-bound at 16 % of the MFMA peak;
+//   * accumulators are kept TRANSPOSED (rows = output channels, lane = pixel), so a lane owns 4 consecutive
+//     channels per register quad: the tile is bounced through wave-private LDS as fp16 and leaves as 16-byte
+//     row-contiguous stores with a 16-byte residual read (the old 2-byte stores cost ~135 us per 84 MB tensor).
+#include "common.h"
+
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int BK = 32;          // halfs per K-step: 64-byte LDS rows, 4 x 16-byte chunks
+constexpr int ROWB = BK * 2;
+constexpr int STAGES = 4;
+
+constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (more samples per tile: global loads)
+
+template <int BM, int BN, int WM, int WN, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
+    constexpr int NW = WM * WN, T = NW * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int A_INSTR = BM * 4 / 64, B_INSTR = BN * 4 / 64;     // wave-instructions (1 KiB each) per stage
+    static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
+    constexpr int LA = A_INSTR / NW, LB = (B_INSTR + NW - 1) / NW;  // A / B load slots per wave per stage
+    constexpr int LPS = LA + LB;                                    // loads per stage per wave (uniform)
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int A_BYTES = BM * ROWB;
+    constexpr int RING_BYTES = STAGES * STAGE_BYTES;     // after the ring: bias[BN] then emb rows [RV_MAX][BN], fp32
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int ntn = (a.N + BN - 1) / BN;
+    const int nb = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
+
+    const int Ctot = a.C0 + a.C1;
+    const int cpt = Ctot >> 5;      // 32-wide chunks per tap
+    const int nk = a.K >> 5;
+
+    // ---- this wave's load slots.  A slot i covers wave-instruction (wave + i*NW) of the A tile (16 rows x 64 B);
+    // B slot likewise; a surplus B slot repeats the last instruction (same bytes to the same LDS address: harmless)
+    int a_pix[LA], a_yx[LA], a_off[LA];      // pixel base, (oy,ox), source chunk offset (halfs); pix = -1: row >= M
+    int b_off[LB], b_lds[LB];
+    const int sy = (CONV && a.mode == IG_CONV3_S2) ? 2 : 1;
+    const int up = (CONV && a.mode == IG_CONV3_UP2) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int q = (wave + i * NW) * 64 + lane, r = q >> 2, s = q & 3;
+        a_off[i] = (s ^ ((r >> 2) & 3)) << 3;                       // source-side swizzle (LDS image stays linear)
+        a_pix[i] = -1; a_yx[i] = 0;
+        const int m = m0 + r;
+        if (m < a.M) {
+            if (!CONV) {
+                a_pix[i] = m;
+            } else {
+                const int hw = a.Ho * a.Wo;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                a_pix[i] = b * a.H * a.W;
+                a_yx[i] = ((oy * sy) << 16) | (ox * sy);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        int idx = wave + i * NW;
+        if (idx >= B_INSTR) idx = B_INSTR - 1;
+        const int q = idx * 64 + lane, r = q >> 2, s = q & 3;
+        b_off[i] = (n0 + r) * a.K + ((s ^ ((r >> 2) & 3)) << 3);
+        b_lds[i] = A_BYTES + idx * 1024;
+    }
+    const unsigned Hu = (unsigned)(a.H << up), Wu = (unsigned)(a.W << up);
+
+    auto stage = [&](int kt, int tap, int cc, int buf) {
+        char* base = smem + buf * STAGE_BYTES;
+        const half_t* src = a.A0;
+        int Cs = a.C0, co = cc << 5;
+        if (co >= a.C0) { src = a.A1; Cs = a.C1; co -= a.C0; }
+        const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const half_t* p = a.zero;
+            if (!CONV) {
+                if (a_pix[i] >= 0) p = src + (size_t)a_pix[i] * Cs + co + a_off[i];
+            } else {
+                // one formula for stride 1 / stride 2 / conv over the nearest-2x-upsampled image
+                const int uy = (a_yx[i] >> 16) + ky, ux = (a_yx[i] & 0xffff) + kx;
+                if (a_pix[i] >= 0 && (unsigned)uy < Hu && (unsigned)ux < Wu)
+                    p = src + (size_t)(a_pix[i] + (uy >> up) * a.W + (ux >> up)) * Cs + co + a_off[i];
+            }
+            glds16(p, base + (wave + i * NW) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) glds16(a.Wt + (size_t)b_off[i] + ((size_t)kt << 5), base + b_lds[i]);
+    };
+
+    // accumulators, TRANSPOSED: acc[nj][mi] = W-tile(nj) x X-tile(mi)^T ; row = channel, lane column = pixel
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    const int lrow = lane & 31, lh = lane >> 5, swz = (lrow >> 2) & 3;
+    int koff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) koff[ks] = lrow * ROWB + (((ks * 2 + lh) ^ swz) << 4);
+
+    // ---- prologue: STAGES-1 stages in flight
+    int tap = 0, cc = 0;
+    auto advance = [&]() { if (++cc == cpt) { cc = 0; ++tap; } };
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        if (s < nk) { stage(s, tap, cc, s); advance(); }
+    }
+
+    // ---- epilogue operands (bias, per-sample emb rows) into LDS now, so the epilogue never waits on global loads
+    float* bias_l = (float*)(smem + RING_BYTES);
+    float* rv_l = bias_l + BN;
+    const int rps = a.rows_per_sample;
+    const int smp0 = m0 / rps;
+    const int last_row = min(m0 + BM, a.M) - 1;
+    const int nsmp = a.rowvec ? last_row / rps - smp0 + 1 : 0;
+    const bool rv_in_lds = nsmp <= RV_MAX;
+    for (int c = tid; c < BN; c += T) bias_l[c] = a.bias ? a.bias[n0 + c] : 0.f;
+    if (a.rowvec && rv_in_lds)
+        for (int c = tid; c < nsmp * BN; c += T) {
+            const int sidx = c / BN, ch = c - sidx * BN;
+            rv_l[c] = a.rowvec[(size_t)(smp0 + sidx) * a.rv_stride + n0 + ch];
+        }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt must have landed: at most the two younger stages of THIS wave may still be in flight
+        const int younger = min(nk - 1 - kt, STAGES - 2);
+        if (younger >= 2) wait_vmcnt<2 * LPS>();
+        else if (younger == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my fragment reads of step kt-1 are done (WAR below)
+        __builtin_amdgcn_s_barrier();
+        // every wave's part of stage kt is in LDS, and nobody still reads buffer (kt-1) % STAGES: refill it
+        if (kt + STAGES - 1 < nk) { stage(kt + STAGES - 1, tap, cc, (kt + STAGES - 1) % STAGES); advance(); }
+
+        const char* As = smem + (kt % STAGES) * STAGE_BYTES + (wm * TM) * ROWB;
+        const char* Bs = smem + (kt % STAGES) * STAGE_BYTES + A_BYTES + (wn * TN) * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 xf[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xf[i] = *(const h8*)(As + i * 32 * ROWB + koff[ks]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *(const h8*)(Bs + j * 32 * ROWB + koff[ks]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // acc[j][i][r]: channel = n0 + wn*TN + j*32 + (r&3) + 8*(r>>2) + 4*lh ; pixel = m0 + wm*TM + i*32 + lrow
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // all waves are out of the K loop: the ring is free for staging
+    constexpr int OUT_TN = GEGLU ? TN / 2 : TN;          // output channels this wave produces
+    constexpr int PITCH = OUT_TN * 2 + 8;                // wave-private staging tile: 32 pixels x OUT_TN fp16
+    constexpr int CPR = OUT_TN / 8;                      // 16-byte chunks per pixel row
+    constexpr int WB_IT = (32 * CPR + 63) / 64;          // writeback iterations per lane
+    static_assert(!GEGLU || NI % 2 == 0, "GEGLU needs value/gate tile pairs");
+    char* cst = smem + wave * (32 * PITCH);
+    const int ocol0 = GEGLU ? ((n0 + wn * TN) >> 1) : (n0 + wn * TN);   // first output column of this wave
+    const int nvalid = GEGLU ? a.N / 2 : a.N;                            // valid output columns overall
+    const float* bw = bias_l + wn * TN;                                  // this wave's slice of the staged bias
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = m0 + wm * TM + i * 32 + lrow;     // this lane's pixel
+        const int bsmp = (a.rowvec && row < a.M) ? row / rps : smp0;
+        const float* rw = rv_l + (bsmp - smp0) * BN + wn * TN;
+        // ---- registers -> (bias, emb, activation, scale) -> fp16 -> LDS [pixel][channel]
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (GEGLU && (j & 1)) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int wc = j * 32 + 8 * g + 4 * lh;                   // packed channel inside the wave tile
+                const f32x4 bq = *(const f32x4*)(bw + wc);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e] + bq[e];
+                if (a.rowvec) {
+                    if (rv_in_lds) {
+                        const f32x4 rq = *(const f32x4*)(rw + wc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rq[e];
+                    } else if (row < a.M) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += a.rowvec[(size_t)bsmp * a.rv_stride + n0 + wn * TN + wc + e];
+                    }
+                }
+                if (a.act == ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                } else if (a.act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if constexpr (GEGLU) {
+                    const f32x4 gq = *(const f32x4*)(bw + wc + 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j | 1][i][g * 4 + e] + gq[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= a.scale;
+                const int oc = GEGLU ? (j >> 1) * 32 + 8 * g + 4 * lh : wc;   // output channel inside the wave tile
+                if (a.out_kind == OUT_F16) {
+                    h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *(h4*)(cst + lrow * PITCH + oc * 2) = pk;
+                } else if (row < a.M && ocol0 + oc < nvalid) {
+                    // direct paths (rare outputs): lane = pixel, 4 consecutive channels
+                    const int ch = ocol0 + oc;
+                    if (a.out_kind == OUT_F32) {
+                        f32x4 pk = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)((float*)a.out + (size_t)row * a.ld_out + ch) = pk;
+                    } else {
+                        const int b = row / rps, t = row - b * rps;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const size_t off = ((size_t)b * nvalid + ch + e) * a.ld_out + t;
+                            if (a.out_kind == OUT_F16_T) ((half_t*)a.out)[off] = (half_t)v[e];
+                            else ((float*)a.out)[off] = v[e];
+                        }
+                    }
+                }
+            }
+        }
+        if (a.out_kind == OUT_F16) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private tile: no barrier needed
+            // ---- LDS -> (+ residual) -> 16-byte row-contiguous global stores; all loads first, then all stores
+            h8 v[WB_IT], rr[WB_IT];
+            size_t goff[WB_IT];
+            bool ok[WB_IT];
+#pragma unroll
+            for (int it = 0; it < WB_IT; ++it) {
+                const int c = lane + it * 64;
+                const int pr = c / CPR, ck = c - pr * CPR;
+                const int grow = m0 + wm * TM + i * 32 + pr;
+                const int gcol = ocol0 + ck * 8;
+                ok[it] = c < 32 * CPR && grow < a.M && gcol < nvalid;
+                goff[it] = (size_t)grow * a.ld_out + gcol;
+                if (ok[it]) {
+                    const char* sp = cst + pr * PITCH + ck * 16;
+                    const h4 lo = *(const h4*)sp, hi = *(const h4*)(sp + 8);
+                    v[it] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (a.resid) rr[it] = *(const h8*)(a.resid + (size_t)grow * a.ld_res + gcol);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < WB_IT; ++it) {
+                if (ok[it]) {
+                    if (a.resid) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[it][e] = (half_t)((float)v[it][e] + (float)rr[it][e]);
+                    }
+                    *(h8*)((half_t*)a.out + goff[it]) = v[it];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV, bool GEGLU>
+int launch2(const IgemmArgs& a, hipStream_t s) {
+    constexpr int ring = STAGES * (BM + BN) * ROWB;
+    constexpr int smem = ring + (1 + RV_MAX) * BN * 4;      // + staged bias and emb rows
+    static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    auto k = igemm2_kernel<BM, BN, WM, WN, CONV, GEGLU>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(WM * WN * 64), smem, s, a);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}
+template <int BM, int BN, int WM, int WN, bool GEGLU>
+int launch2m(const IgemmArgs& a, hipStream_t s) {
+    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, false, GEGLU>(a, s) : launch2<BM, BN, WM, WN, true, GEGLU>(a, s);
+}
+
+}  // namespace
+
+// cfg: 0 = 256x320, 1 = 256x256 (GEGLU-capable), 2 = 128x320
+int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
+    if ((a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return FGDM_ERR_ARG;
+    const int bn = cfg == 1 ? 256 : 320;
+    if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
+    if (a.act == ACT_GEGLU && cfg != 1) return FGDM_ERR_ARG;
+    switch (cfg) {
+        case 0: return launch2m<256, 320, 4, 2, false>(a, s);
+        case 1: return a.act == ACT_GEGLU ? launch2m<256, 256, 4, 2, true>(a, s) : launch2m<256, 256, 4, 2, false>(a, s);
+        case 2: return launch2m<128, 320, 4, 2, false>(a, s);
+        default: return FGDM_ERR_ARG;
+    }
+}

@@ -124,6 +124,12 @@ int fgdm_op_conv2d(const void* x0, int C0, const void* x1, int C1, const float* 
                    int upsample, int act, float scale, void* out, void* stream);
 int fgdm_op_linear(const void* x, const float* w, const float* bias, const void* resid, int M, int K, int N,
                    int act, int out_kind, int rows_per_sample, int ld_out, void* out, void* stream);
+/* Tuning aids: force the implicit-GEMM tile configuration process-wide (0 = automatic; 1-3 = 2-stage kernel
+ * 128x128 / 128x64 / 64x64; 4-6 = pipelined kernel 256x320 / 256x256 / 128x320), and time one conv / linear shape on
+ * random data (average device milliseconds over `iters` launches). */
+int fgdm_debug_force_igemm_cfg(int cfg);
+int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample, int act,
+                     int use_resid, int cfg, int iters, float* avg_ms);
 int fgdm_op_groupnorm(const void* x0, int C0, const void* x1, int C1, int B, int HW, const float* gamma,
                       const float* beta, float eps, int silu, void* out, void* stream);
 int fgdm_op_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps,

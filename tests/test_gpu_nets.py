@@ -125,3 +125,23 @@ def test_ddim_trajectory_vs_reference_sampler(small_engine):
                                    tab['timesteps'], tab['alphas'], tab['alphas_prev'], tab['sqrt_one_minus_alphas'],
                                    flags=_lib.FLAG_NO_CONTROL)
     assert report('10-step DDIM CFG7.5 trajectory vs reference sampler+UNet', relerr(out.cpu(), g['out']), 1e-2) < 1e-2
+
+
+def test_pipelined_kernels_agree_with_two_stage_kernels(small_engine):
+    """At a batch large enough for the automatic tile choice to pick the pipelined big-tile kernels (igemm2.hip),
+    the network output must agree with the run forced onto the 2-stage 128x128 kernel (both fp32-accumulate;
+    they differ only in summation order and in where fp16 rounding of the epilogue happens)."""
+    from fgdm_amd import _lib
+    lib = _lib.load()
+    B = 8
+    x = torch.from_numpy(synth.latents(B, 64, 64, seed=21))
+    ctx = torch.from_numpy(synth.context(B, seed=22))
+    t = torch.full((B,), 601, dtype=torch.long)
+    small_engine.set_hint(0, torch.from_numpy(synth.hint(B, 512, seed=23)).cuda())
+    auto = small_engine.apply_model(x, t, ctx).cpu()
+    try:
+        lib.fgdm_debug_force_igemm_cfg(1)
+        ref = small_engine.apply_model(x, t, ctx).cpu()
+    finally:
+        lib.fgdm_debug_force_igemm_cfg(0)
+    assert report('auto tiles (pipelined kernels) vs forced 2-stage kernel, B=8 64x64', relerr(auto, ref), 1e-3) < 1e-3

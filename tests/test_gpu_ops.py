@@ -228,3 +228,70 @@ def test_sampler_kernels(lib):
     got = E.ancestral_step(x, ec, 1.7, 1.3, 0.2, 0.8, 0.4, nz)
     x0 = 1.7 * x - 1.3 * ec
     assert relerr(got.cpu(), (0.2 * x0 + 0.8 * x + 0.4 * nz).cpu()) < 1e-6
+
+
+# ----------------------------------------------------------------------------- pipelined big-tile kernel (igemm2.hip)
+BIG_CASES = [
+    # cfg, B, H, W, C0, C1, Cout, ksize, stride, up, act, extras
+    (4, 3, 16, 16, 320, 0, 320, 3, 1, 0, 0, 'cfg4 conv + rowvec + resid, M tail'),
+    (4, 2, 16, 16, 640, 320, 640, 3, 1, 0, 1, 'cfg4 concat + silu'),
+    (4, 2, 16, 16, 320, 0, 640, 3, 2, 0, 0, 'cfg4 stride 2'),
+    (4, 2, 8, 8, 640, 0, 640, 3, 1, 1, 0, 'cfg4 upsample'),
+    (4, 2, 16, 16, 1280, 640, 320, 1, 1, 0, 0, 'cfg4 conv1x1 concat'),
+    (6, 3, 8, 8, 320, 0, 1280, 3, 1, 0, 2, 'cfg6 conv relu + rowvec + resid, M tail'),
+    (6, 1, 3, 5, 64, 0, 320, 3, 1, 0, 0, 'cfg6 tiny odd image'),
+    (6, 2, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 'cfg6 decoder concat'),
+]
+
+
+@pytest.mark.parametrize('case', BIG_CASES, ids=[c[-1] for c in BIG_CASES])
+def test_conv_pipelined_kernel(lib, case):
+    cfg = case[0]
+    assert lib.fgdm_debug_force_igemm_cfg(cfg) == 0
+    try:
+        inner = case[1:-1] + (case[-1] + (' rowvec' if 'rowvec' in case[-1] else ''),)
+        test_conv(lib, inner)
+    finally:
+        lib.fgdm_debug_force_igemm_cfg(0)
+
+
+def test_linear_pipelined_kernel(lib):
+    try:
+        M, K = 300, 320
+        x = h16(rnd((M, K), 71))
+        xd = x.half().cuda()
+        # GEGLU through the 256x256 configuration
+        N = 2560
+        w, b = h16(rnd((N, K), 72, 1 / np.sqrt(K))), rnd((N,), 73, 0.1)
+        y = F.linear(x, w, b)
+        a, g = y.chunk(2, dim=-1)
+        out = torch.empty(M, N // 2, dtype=torch.half, device='cuda')
+        wd, bd = w.cuda(), b.cuda()
+        lib.fgdm_debug_force_igemm_cfg(5)
+        assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
+        assert relerr(out.float().cpu(), a * F.gelu(g)) < TOL
+        # plain / fp32 / transposed outputs through 256x320 and 128x320
+        N2 = 640
+        w2, b2 = w[:N2].contiguous(), b[:N2].contiguous()
+        w2d, b2d = w2.cuda(), b2.cuda()
+        ref = F.linear(x, w2, b2)
+        res = h16(rnd((M, N2), 74))
+        resd = res.half().cuda()
+        for cfg in (4, 6):
+            lib.fgdm_debug_force_igemm_cfg(cfg)
+            out = torch.empty(M, N2, dtype=torch.half, device='cuda')
+            assert lib.fgdm_op_linear(_p(xd), _p(w2d), _p(b2d), _p(resd), M, K, N2, 0, 0, 0, 0, _p(out), _st()) == 0
+            assert relerr(out.float().cpu(), ref + res) < TOL, cfg
+            out32 = torch.empty(M, N2, dtype=torch.float32, device='cuda')
+            assert lib.fgdm_op_linear(_p(xd), _p(w2d), _p(b2d), None, M, K, N2, 0, 1, 0, 0, _p(out32), _st()) == 0
+            assert relerr(out32.cpu(), ref) < 2e-5, cfg
+            for rps, Bt in ((100, 3), (77, 2)):
+                Mt = rps * Bt
+                ld = (rps + 63) // 64 * 64
+                outT = torch.zeros(Bt, N2, ld, dtype=torch.half, device='cuda')
+                xt = x[:Mt].half().cuda()
+                assert lib.fgdm_op_linear(_p(xt), _p(w2d), _p(b2d), None, Mt, K, N2, 0, 3, rps, ld, _p(outT), _st()) == 0
+                want = ref[:Mt].view(Bt, rps, N2).permute(0, 2, 1)
+                assert relerr(outT[:, :, :rps].float().cpu(), want) < TOL, (cfg, rps)
+    finally:
+        lib.fgdm_debug_force_igemm_cfg(0)
