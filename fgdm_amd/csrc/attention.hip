@@ -9,8 +9,16 @@
 //                   holds one query column -> the softmax row reduction is in-lane + one cross-half shuffle.
 //   O^T += Vt P^T : the S^T accumulator registers, converted to fp16, ARE the B operand (k order permuted as
 //                   16s + 8(j>>2) + 4h + (j&3)); the A operand reads Vt from LDS with the same key permutation.
-// Online softmax state (m, l) and the O^T accumulators are per-lane scalars of that lane's query.
+// The softmax is VALU-bound at d = 40 (one v_exp per score against 14 MFMAs per 64 keys), so the VALU work is cut:
+//   * the row sum l = sum_k p rides on the MFMA: the spare rows of the padded O^T tile (d = 40 -> 64, 80 -> 96)
+//     get a row of ONES in the Vt LDS tile, so O^T[row D] accumulates sum_k fp16(p) -- exactly the normaliser of
+//     the fp16 probabilities used in the numerator -- and is rescaled together with O for free;
+//   * deferred-max rescale: the running max is only raised (and O rescaled) when some query of the wave exceeds it
+//     by more than 2^8; p <= 256 stays exact-range in fp16 and the final division by l cancels the offset;
+//   * K / Vt tiles are double-buffered in LDS and prefetched into registers one tile ahead (one barrier per tile).
 #include "common.h"
+
+#define ATT_THR 8.0f
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q, int ldq,
@@ -21,27 +29,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     constexpr int DP = (D + 15) / 16 * 16;   // QK^T contraction length, padded to MFMA K
     constexpr int NKS = DP / 16;
     constexpr int DT = (D + 31) / 32;         // 32-row tiles of O^T
+    constexpr bool ONES = (DT * 32 > D);      // a spare O^T row exists: row D carries the softmax denominator
     constexpr int KS = DP * 2 + 16;           // K-tile row stride in bytes: odd multiple of 16 -> b128 conflict-free
     constexpr int VS = 64 * 2 + 8;            // Vt-tile row stride in bytes: 34 dwords -> b64 conflict-free
     constexpr int DC = D / 8;                 // 16-byte chunks per K row
-    __shared__ __attribute__((aligned(16))) char Ks[64 * KS];
-    __shared__ __attribute__((aligned(16))) char Vs[DT * 32 * VS];
+    constexpr int KCH = (64 * DC + 255) / 256;   // K chunks per thread per tile
+    constexpr int VCH = (D * 8 + 255) / 256;     // Vt chunks per thread per tile
+    constexpr int KBYTES = 64 * KS, VBYTES = DT * 32 * VS;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + lq;
 
-    // zero the K pad columns [D, DP) once (tile loads never touch them) and the Vt pad rows [D, DT*32)
-    if constexpr (DP > D) {
-        for (int i = tid; i < 64 * (DP - D) / 8; i += 256) {
-            const int key = i / ((DP - D) / 8), c = i % ((DP - D) / 8);
-            *(h8*)(Ks + key * KS + (D + c * 8) * 2) = (h8)(half_t)0;
+    // pad regions of both buffers, written once: K pad columns [D, DP) = 0; Vt pad rows [D, DT*32) = 0, row D = 1
+    for (int buf = 0; buf < 2; ++buf) {
+        char* Ksb = smem + buf * (KBYTES + VBYTES);
+        char* Vsb = Ksb + KBYTES;
+        if constexpr (DP > D) {
+            for (int i = tid; i < 64 * (DP - D) / 8; i += 256) {
+                const int key = i / ((DP - D) / 8), c = i % ((DP - D) / 8);
+                *(h8*)(Ksb + key * KS + (D + c * 8) * 2) = (h8)(half_t)0;
+            }
         }
-    }
-    for (int i = tid; i < (DT * 32 - D) * 16; i += 256) {
-        const int r = D + i / 16, c = i % 16;
-        *(h4*)(Vs + r * VS + c * 8) = (h4)(half_t)0;
+        for (int i = tid; i < (DT * 32 - D) * 16; i += 256) {
+            const int r = D + i / 16, c = i % 16;
+            *(h4*)(Vsb + r * VS + c * 8) = (r == D) ? (h4)(half_t)1 : (h4)(half_t)0;
+        }
     }
 
     // Q^T fragments (B operand): lane holds Q[q][16s + 8h .. +7]
@@ -58,27 +73,58 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // l_run only used when there is no spare row (D = 160)
 
     const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
     const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
 
+    // register prefetch of one K / Vt tile
+    h8 kreg[KCH], vreg[VCH];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) {
+            const int i = tid + u * 256;
+            const int key = i / DC, c = i - key * DC;
+            kreg[u] = (h8)(half_t)0;
+            if (i < 64 * DC && k0 + key < Tk) kreg[u] = *(const h8*)(Kb + (size_t)(k0 + key) * ldk + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < VCH; ++u) {
+            const int i = tid + u * 256;
+            if (i < D * 8) vreg[u] = *(const h8*)(Vb + (size_t)(i >> 3) * ldvt + k0 + (i & 7) * 8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* Ksb = smem + buf * (KBYTES + VBYTES);
+        char* Vsb = Ksb + KBYTES;
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) {
+            const int i = tid + u * 256;
+            const int key = i / DC, c = i - key * DC;
+            if (i < 64 * DC) *(h8*)(Ksb + key * KS + c * 16) = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < VCH; ++u) {
+            const int i = tid + u * 256;
+            if (i < D * 8) {
+                const int r = i >> 3, c = i & 7;
+                const h8 v = vreg[u];
+                h4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+                *(h4*)(Vsb + r * VS + c * 16) = lo;
+                *(h4*)(Vsb + r * VS + c * 16 + 8) = hi;
+            }
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    int cur = 0;
     for (int k0 = 0; k0 < Tk; k0 += 64) {
-        __syncthreads();   // previous tile fully consumed (also orders the pad-zeroing before the first tile)
-        for (int i = tid; i < 64 * DC; i += 256) {
-            const int key = i / DC, c = i % DC;
-            h8 v = (h8)(half_t)0;
-            if (k0 + key < Tk) v = *(const h8*)(Kb + (size_t)(k0 + key) * ldk + c * 8);
-            *(h8*)(Ks + key * KS + c * 16) = v;
-        }
-        for (int i = tid; i < D * 8; i += 256) {
-            const int r = i >> 3, c = i & 7;
-            const h8 v = *(const h8*)(Vb + (size_t)r * ldvt + k0 + c * 8);
-            h4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-            *(h4*)(Vs + r * VS + c * 16) = lo;
-            *(h4*)(Vs + r * VS + c * 16 + 8) = hi;
-        }
-        __syncthreads();
+        const bool more = k0 + 64 < Tk;
+        if (more) load_tile(k0 + 64);      // global loads fly while this tile is computed
+        __syncthreads();                   // buffer `cur` is complete; buffer cur^1 is no longer read by anyone
+        const char* Ks = smem + cur * (KBYTES + VBYTES);
+        const char* Vs = Ks + KBYTES;
 
         // ---- S^T = K Q^T for two 32-key sub-tiles
         f32x16 sacc[2];
@@ -101,33 +147,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
                     if (key >= Tk) sacc[sub][r] = -INFINITY;
                 }
         }
-        // ---- online softmax for this lane's query (keys split over the two lane halves)
-        float mx = sacc[0][0];
+        // ---- online softmax for this lane's query (keys split over the two lane halves), log2 domain
+        float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2e;
+        // raise the running max only when some query of this wave outgrew it by more than ATT_THR (deferred rescale)
+        if (!__all(mx - m_run <= ATT_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2e);
-        const float mb = m_new * sl2e;
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[sub][r] * sl2e - mb);
+                const float p = __builtin_amdgcn_exp2f(sacc[sub][r] * sl2e - m_run);
                 sacc[sub][r] = p;
-                psum += p;
+                if constexpr (!ONES) psum += p;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        if constexpr (!ONES) l_run += psum;
 
-        // ---- O^T += Vt P^T
+        // ---- O^T += Vt P^T   (with ONES: row D of O^T accumulates sum_k p)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -145,9 +192,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
                 }
             }
         }
+        if (more) store_tile(cur ^ 1);     // safe: everyone passed this iteration's barrier after reading cur^1
+        cur ^= 1;
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if constexpr (ONES) {
+        // row D of O^T lives in tile D/32, register (D%32 -> (r&3)+8(r>>2)+4h): fetch it from the lane half that owns it
+        constexpr int rr = D % 32;
+        constexpr int reg = (rr & 3) + 4 * (rr >> 3);     // register index within the half that has 4*lh == rr & 4
+        constexpr int owner_half = (rr >> 2) & 1;
+        const float mine = oacc[D / 32][reg];
+        const float other = __shfl_xor(mine, 32);
+        l_tot = (lh == owner_half) ? mine : other;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
     const float inv = 1.0f / l_tot;
     if (q < T) {
         half_t* op = O + ((size_t)b * T + q) * ldo + head * D;
