@@ -42,6 +42,8 @@ struct IgemmArgs {
     int rows_per_sample;   // Ho*Wo (LINEAR: tokens per sample) -> sample index b = m / rows_per_sample
     float scale;           // (acc + bias + rowvec -> act) * scale + resid
     int force_cfg;         // 0 = pick automatically; k > 0 = tile configuration k-1 (tuning / benchmarks)
+    int debug;             // ablation switches for tools/bench_igemm.py only: 1 = skip global->LDS loads in the K loop,
+                           // 2 = skip the MFMAs, 4 = skip the epilogue stores (results are then meaningless)
 };
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s);

@@ -415,7 +415,12 @@ struct fgdm_engine {
         const int K = implicit ? 9 * Cin : roundup(9 * cp, 64);
         std::vector<int> kmap(K, -1);
         for (int tap = 0; tap < 9; ++tap)
-            for (int c = 0; c < Cin; ++c) kmap[tap * cp + c] = c * 9 + tap;   // source index within a row: [Cin][3][3]
+            for (int c = 0; c < Cin; ++c) {
+                // implicit GEMM: k = (c / 64 * 9 + tap) * 64 + c % 64  (64-channel chunk outermost, then tap: the order the
+                // kernels walk K, see igemm2.hip); im2col path: k = tap * cin_pad + c.  Source row layout is [Cin][3][3].
+                const int k = implicit ? ((c >> 6) * 9 + tap) * 64 + (c & 63) : tap * cp + c;
+                kmap[k] = c * 9 + tap;
+            }
         g.im2col = !implicit;
         g.cin_pad = cp;
         return pack_rows(g, {{w->host.data(), N}}, Cin * 9, K, kmap, {b->host.data()}, false);
@@ -1210,7 +1215,10 @@ int fgdm_op_conv2d(const void* x0, int C0, const void* x1, int C1, const float* 
     for (int n = 0; n < Cout; ++n) {
         bp[n] = bh[n];
         for (int tap = 0; tap < taps; ++tap)
-            for (int c = 0; c < Cin; ++c) pk[(size_t)n * K + tap * Cin + c] = (half_t)wh[((size_t)n * Cin + c) * taps + tap];
+            for (int c = 0; c < Cin; ++c) {
+                const size_t k = taps == 9 ? (size_t)((c >> 6) * 9 + tap) * 64 + (c & 63) : (size_t)c;
+                pk[(size_t)n * K + k] = (half_t)wh[((size_t)n * Cin + c) * taps + tap];
+            }
     }
     TmpDev tmp;
     IgemmArgs a{};
@@ -1302,7 +1310,7 @@ int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, i
     if (!a.A0 || !a.Wt || !a.bias || !a.zero) return FGDM_ERR_NOMEM;
     a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.mode = mode;
     a.M = (int)M; a.N = Cout; a.K = K; a.act = act; a.out_kind = OUT_F16; a.out = out; a.ld_out = nout;
-    a.rows_per_sample = Ho * Wo; a.scale = 1.f; a.force_cfg = cfg;
+    a.rows_per_sample = Ho * Wo; a.scale = 1.f; a.force_cfg = cfg & 0xff; a.debug = cfg >> 8;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     int rc = FGDM_OK;

@@ -23,7 +23,14 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU via Abramowitz-Stegun 7.1.26 erfc (|abs err| <= 1.5e-7), no 1 - erf cancellation (see igemm2.hip)
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float pe = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) {
@@ -85,6 +92,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
     auto stage = [&](int kt, int tap, int cc, int buf) {
         char* As = smem + buf * STAGE;
         char* Bs = As + A_BYTES;
+        // K-step order for convolutions: 64-channel chunk outermost, the 9 taps inside (see igemm2.hip); `cc` = chunk
         const half_t* src = a.A0;
         int Cs = a.C0, co = cc << 6;
         if (co >= a.C0) { src = a.A1; Cs = a.C1; co -= a.C0; }
@@ -140,7 +148,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // tile kt has landed for every wave; buffer (kt+1)&1 is no longer being read
         if (kt + 1 < nk) {
-            if (++cc == cpt) { cc = 0; ++tap; }
+            if (a.mode == IG_LINEAR) ++cc;
+            else if (++tap == 9) { tap = 0; ++cc; }
             stage(kt + 1, tap, cc, (kt + 1) & 1);
         }
         const char* As = smem + (kt & 1) * STAGE + (wm * TM) * 128;

@@ -16,11 +16,29 @@
 
 namespace {
 
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const GLB_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+// global -> LDS DMA, 16 bytes per lane, issued through inline asm.  hipcc's wait-count pass treats the builtin form
+// (__builtin_amdgcn_global_load_lds) as a FLAT access to both address spaces ("pending flat"), after which EVERY
+// lgkmcnt / vmcnt wait it inserts is a full drain to 0 -- with loads permanently in flight that serialised each
+// stage's 14 fragment reads against its MFMAs.  The asm form is invisible to the pass: completion is tracked by the
+// hand-counted s_waitcnt vmcnt(N) in the K loop.  M0 = wave-uniform LDS byte address; saved / restored around the op.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_wave_addr)
+                 : "memory");
 }
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const void*)p; }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (ldm/modules/attention.py:43-44) with erfc evaluated by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7,
+// far below fp16 output resolution); written without the 1 - erf cancellation for negative x.  13 VALU ops vs ~32.
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float pe = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);     // erfc(|x| / sqrt 2)
+    return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -28,11 +46,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 constexpr int BK = 32;          // halfs per K-step: 64-byte LDS rows, 4 x 16-byte chunks
 constexpr int ROWB = BK * 2;
-constexpr int STAGES = 4;
 
 constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (more samples per tile: global loads)
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool GEGLU>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, T = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -98,10 +115,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     }
     const unsigned Hu = (unsigned)(a.H << up), Wu = (unsigned)(a.W << up);
 
+    // K-step order (CONV): 64-channel chunk outermost, then the 9 taps, then the two 32-channel halves -- so the nine
+    // shifted re-reads of a (pixel, channel-chunk) happen in consecutive steps and hit L1/L2 instead of travelling
+    // to the Infinity Cache (the LDS fill path, ~70 GB/s per CU from L2 vs ~33 from MALL, is what bounds this
+    // kernel).  `cc` = channel offset of the step, `tap` = 0..8.  Weights are packed in the same order.
     auto stage = [&](int kt, int tap, int cc, int buf) {
-        char* base = smem + buf * STAGE_BYTES;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(smem) + buf * STAGE_BYTES);
         const half_t* src = a.A0;
-        int Cs = a.C0, co = cc << 5;
+        int Cs = a.C0, co = cc;
         if (co >= a.C0) { src = a.A1; Cs = a.C1; co -= a.C0; }
         const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
@@ -115,10 +136,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 if (a_pix[i] >= 0 && (unsigned)uy < Hu && (unsigned)ux < Wu)
                     p = src + (size_t)(a_pix[i] + (uy >> up) * a.W + (ux >> up)) * Cs + co + a_off[i];
             }
+            if (a.debug & 8) p = a.zero;                 // ablation: same instruction stream, no memory footprint
             glds16(p, base + (wave + i * NW) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) glds16(a.Wt + (size_t)b_off[i] + ((size_t)kt << 5), base + b_lds[i]);
+        for (int i = 0; i < LB; ++i)
+            glds16((a.debug & 8) ? a.zero : a.Wt + (size_t)b_off[i] + ((size_t)kt << 5), base + b_lds[i]);
     };
 
     // accumulators, TRANSPOSED: acc[nj][mi] = W-tile(nj) x X-tile(mi)^T ; row = channel, lane column = pixel
@@ -136,8 +159,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     for (int ks = 0; ks < 2; ++ks) koff[ks] = lrow * ROWB + (((ks * 2 + lh) ^ swz) << 4);
 
     // ---- prologue: STAGES-1 stages in flight
-    int tap = 0, cc = 0;
-    auto advance = [&]() { if (++cc == cpt) { cc = 0; ++tap; } };
+    int tap = 0, cc = 0;      // tap index, channel offset of the next stage to issue
+    auto advance = [&]() {
+        if (!CONV) { cc += 32; return; }
+        if (cc & 32) {                       // second half of the 64-chunk done: next tap (or next chunk)
+            if (++tap == 9) { tap = 0; cc += 32; } else { cc -= 32; }
+        } else {
+            cc += 32;
+        }
+    };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
         if (s < nk) { stage(s, tap, cc, s); advance(); }
@@ -158,34 +188,56 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
             rv_l[c] = a.rowvec[(size_t)(smp0 + sidx) * a.rv_stride + n0 + ch];
         }
 
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt must have landed: at most the two younger stages of THIS wave may still be in flight
-        const int younger = min(nk - 1 - kt, STAGES - 2);
-        if (younger >= 2) wait_vmcnt<2 * LPS>();
-        else if (younger == 1) wait_vmcnt<LPS>();
+    // ---- K loop: one stage (BK = 32) and ONE barrier per iteration; STAGES-1 stages of loads in flight.
+    // Tried and measured on MI355X (tools/bench_igemm.py, L0 conv 320->320, 256x320 tile):
+    //   all 14 fragment reads hoisted ahead of one 20-MFMA cluster with counted lgkmcnt waits (this version)  779 TF/s
+    //   reads of the next half-stage issued under the MFMAs of the current one (barrier mid-stage)             685 TF/s
+    //   wave groups 0-3 / 4-7 staggered by one barrier phase (2 barriers per stage)                           734 TF/s
+    //     (the stagger lifts the no-global-load ablation from 1044 to 1187 TF/s but loses it again to the LDS-DMA
+    //      fill path: 207 us compute-only, +46 us for the load instructions alone, +76 us for their memory traffic)
+    auto wait_stage = [&](int k_needed) {     // stage k_needed landed; younger stages of this wave may stay in flight
+        const int younger = min(nk - 1 - k_needed, STAGES - 2);
+        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LPS>();
+        else if (STAGES >= 3 && younger == 1) wait_vmcnt<LPS>();
         else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my fragment reads of step kt-1 are done (WAR below)
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_stage(kt);
+        // my fragment reads of step kt-1 are done (WAR below).  The BUILTIN form (0xC07F = lgkmcnt(0) only) is modelled by
+        // hipcc's wait-count pass, so the ds_reads that follow get COUNTED lgkmcnt waits.
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         // every wave's part of stage kt is in LDS, and nobody still reads buffer (kt-1) % STAGES: refill it
-        if (kt + STAGES - 1 < nk) { stage(kt + STAGES - 1, tap, cc, (kt + STAGES - 1) % STAGES); advance(); }
-
+        if (kt + STAGES - 1 < nk && !(a.debug & 1)) { stage(kt + STAGES - 1, tap, cc, (kt + STAGES - 1) % STAGES); advance(); }
         const char* As = smem + (kt % STAGES) * STAGE_BYTES + (wm * TM) * ROWB;
         const char* Bs = smem + (kt % STAGES) * STAGE_BYTES + A_BYTES + (wn * TN) * ROWB;
+        h8 xf[2][MI], wf[2][NI];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 xf[MI], wf[NI];
+        for (int ks = 0; ks < 2; ++ks) {     // read order = MFMA consumption order
 #pragma unroll
-            for (int i = 0; i < MI; ++i) xf[i] = *(const h8*)(As + i * 32 * ROWB + koff[ks]);
+            for (int i = 0; i < MI; ++i) xf[ks][i] = *(const h8*)(As + i * 32 * ROWB + koff[ks]);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) wf[j] = *(const h8*)(Bs + j * 32 * ROWB + koff[ks]);
+            for (int j = 0; j < NI; ++j) wf[ks][j] = *(const h8*)(Bs + j * 32 * ROWB + koff[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep all reads ahead of the MFMA cluster
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
-        }
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
     }
 
+    if (a.debug & 4) {      // ablation: keep the accumulators alive but skip the whole epilogue
+        float sink = 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) sink += acc[j][i][0] + acc[j][i][15];
+        if (sink == 12345.678f) ((float*)a.out)[0] = sink;
+        return;
+    }
     // ---------------------------------------------------------------- epilogue
     // acc[j][i][r]: channel = n0 + wn*TN + j*32 + (r&3) + 8*(r>>2) + 4*lh ; pixel = m0 + wm*TM + i*32 + lrow
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -298,14 +350,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool GEGLU>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU>
 int launch2(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4;      // + staged bias and emb rows
     static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto k = igemm2_kernel<BM, BN, WM, WN, CONV, GEGLU>;
+    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -314,23 +366,25 @@ int launch2(const IgemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
-template <int BM, int BN, int WM, int WN, bool GEGLU>
+template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU>
 int launch2m(const IgemmArgs& a, hipStream_t s) {
-    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, false, GEGLU>(a, s) : launch2<BM, BN, WM, WN, true, GEGLU>(a, s);
+    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, STAGES, false, GEGLU>(a, s)
+                               : launch2<BM, BN, WM, WN, STAGES, true, GEGLU>(a, s);
 }
 
 }  // namespace
 
-// cfg: 0 = 256x320, 1 = 256x256 (GEGLU-capable), 2 = 128x320
+// cfg: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320     (all: 8 waves, 4-stage ring)
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if ((a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return FGDM_ERR_ARG;
     const int bn = cfg == 1 ? 256 : 320;
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
-    if (a.act == ACT_GEGLU && cfg != 1) return FGDM_ERR_ARG;
+    const bool g = a.act == ACT_GEGLU;
+    if (g && bn != 256) return FGDM_ERR_ARG;
     switch (cfg) {
-        case 0: return launch2m<256, 320, 4, 2, false>(a, s);
-        case 1: return a.act == ACT_GEGLU ? launch2m<256, 256, 4, 2, true>(a, s) : launch2m<256, 256, 4, 2, false>(a, s);
-        case 2: return launch2m<128, 320, 4, 2, false>(a, s);
+        case 0: return launch2m<256, 320, 4, 2, 4, false>(a, s);
+        case 1: return g ? launch2m<256, 256, 4, 2, 4, true>(a, s) : launch2m<256, 256, 4, 2, 4, false>(a, s);
+        case 2: return launch2m<128, 320, 4, 2, 4, false>(a, s);
         default: return FGDM_ERR_ARG;
     }
 }

@@ -241,6 +241,10 @@ BIG_CASES = [
     (6, 3, 8, 8, 320, 0, 1280, 3, 1, 0, 2, 'cfg6 conv relu + rowvec + resid, M tail'),
     (6, 1, 3, 5, 64, 0, 320, 3, 1, 0, 0, 'cfg6 tiny odd image'),
     (6, 2, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 'cfg6 decoder concat'),
+    (5, 2, 8, 8, 640, 0, 1280, 3, 1, 1, 1, 'cfg5 upsample N=1280 silu'),
+    (4, 1, 4, 4, 64, 0, 320, 3, 1, 0, 0, 'cfg4 K=576 (18 stages), single tile'),
+    (4, 1, 8, 8, 64, 0, 320, 1, 1, 0, 0, 'cfg4 K=64 (2 stages < ring depth)'),
+    (6, 1, 8, 8, 32 * 2, 0, 320, 1, 1, 0, 0, 'cfg6 K=64'),
 ]
 
 
@@ -267,9 +271,11 @@ def test_linear_pipelined_kernel(lib):
         a, g = y.chunk(2, dim=-1)
         out = torch.empty(M, N // 2, dtype=torch.half, device='cuda')
         wd, bd = w.cuda(), b.cuda()
-        lib.fgdm_debug_force_igemm_cfg(5)
-        assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
-        assert relerr(out.float().cpu(), a * F.gelu(g)) < TOL
+        for cfg in (5,):
+            lib.fgdm_debug_force_igemm_cfg(cfg)
+            out.zero_()
+            assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
+            assert relerr(out.float().cpu(), a * F.gelu(g)) < TOL, cfg
         # plain / fp32 / transposed outputs through 256x320 and 128x320
         N2 = 640
         w2, b2 = w[:N2].contiguous(), b[:N2].contiguous()
