@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfgdm_hip.so')
 SOURCES = ['igemm.hip', 'igemm2.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'engine.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
-         '-Wno-unused-variable', '-ffp-contract=fast', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
+         '-Wno-unused-variable', '-ffp-contract=fast', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-fno-honor-nans']
 
 
 def _hipcc():

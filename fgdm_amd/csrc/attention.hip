@@ -40,8 +40,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y;
-    const int q = blockIdx.x * 128 + wave * 32 + lq;
+    // XCD-aware mapping: workgroups b and b+8 share an XCD (and its 4 MiB L2).  Give every XCD a contiguous range of
+    // (batch, head, q-block) triples with the q-block fastest, so all q-blocks of one (batch, head) stream the SAME
+    // K / Vt through ONE L2 instead of eight (PMC: 389 MB fetched per launch against 252 MB of Q+K+V before).
+    const int nqb = (T + 127) / 128;
+    const int nb = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qd = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
+    }
+    const int qblk = logical % nqb, bh = logical / nqb;
+    const int b = bh / H, head = bh - b * H;
+    const int q = qblk * 128 + wave * 32 + lq;
 
     // pad regions of both buffers, written once: K pad columns [D, DP) = 0; Vt pad rows [D, DT*32) = 0, row D = 1
     for (int buf = 0; buf < 2; ++buf) {
@@ -230,7 +241,7 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
     if (B <= 0 || H <= 0 || T <= 0 || Tk <= 0) return FGDM_ERR_ARG;
     if (ldvt < (Tk + 63) / 64 * 64 || (ldvt & 7) || (ldq & 7) || (ldk & 7) || (ldo & 3)) return FGDM_ERR_ARG;
     const float sl2e = 1.4426950408889634f / sqrtf((float)d);
-    const dim3 grid((T + 127) / 128, H, B), block(256);
+    const dim3 grid(((T + 127) / 128) * H * B), block(256);
     switch (d) {
         case 40: hipLaunchKernelGGL(attn_kernel<40>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
         case 80: hipLaunchKernelGGL(attn_kernel<80>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;

@@ -42,13 +42,17 @@ struct IgemmArgs {
     int rows_per_sample;   // Ho*Wo (LINEAR: tokens per sample) -> sample index b = m / rows_per_sample
     float scale;           // (acc + bias + rowvec -> act) * scale + resid
     int force_cfg;         // 0 = pick automatically; k > 0 = tile configuration k-1 (tuning / benchmarks)
+    int splitk;            // > 1: K is split over `splitk` workgroups per tile; fp32 partial tiles go to `ws`
+    float* ws;             //      [splitk][M][N] and igemm_splitk_reduce applies the epilogue (deterministic order)
     int debug;             // ablation switches for tools/bench_igemm.py only: 1 = skip global->LDS loads in the K loop,
                            // 2 = skip the MFMAs, 4 = skip the epilogue stores (results are then meaningless)
 };
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 void igemm_set_force_cfg(int cfg);   // process-wide override of the tile choice (0 = automatic)
-int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s);   // pipelined big-tile kernel (igemm2.hip)
+int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s);
+int igemm_splitk_factor(const IgemmArgs& a);                    // 1 = no split; else the engine must provide a.ws
+int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s);     // out = epilogue(sum_s ws[s])   // pipelined big-tile kernel (igemm2.hip)
 size_t igemm_npad(int n);   // rows the packed weight must provide
 
 // ---------------------------------------------------------------- norms

@@ -555,9 +555,15 @@ struct fgdm_engine {
         if (!a.out) return fail(FGDM_ERR_NOMEM, "gemm: null output (workspace exhausted?)");
         char tag[56] = "";
         if (prof.on) snprintf(tag, sizeof(tag), "igemm M%d N%d K%d mode%d act%d out%d", a.M, a.N, a.K, a.mode, a.act, a.out_kind);
+        a.splitk = igemm_splitk_factor(a);
+        if (a.splitk > 1) {
+            a.ws = (float*)arena.alloc((size_t)a.splitk * a.M * a.N * sizeof(float));
+            if (!a.ws) return fail(FGDM_ERR_NOMEM, "workspace (split-K partials)");
+        }
         prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real, tag);
         const int rc = igemm_launch(a, s);
         prof.end(s);
+        if (a.ws) arena.release(a.ws);
         return rc == FGDM_OK ? rc : fail(rc, "igemm launch failed");
     }
     // conv3x3 (stride 1/2, or on the nearest-2x upsampled input) -> new tensor
@@ -1238,6 +1244,11 @@ int fgdm_op_conv2d(const void* x0, int C0, const void* x1, int C1, const float* 
     a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = K;
     a.act = act; a.out_kind = OUT_F16; a.out = out; a.ld_out = Cout;
     a.rows_per_sample = a.Ho * a.Wo; a.scale = scale;
+    a.splitk = igemm_splitk_factor(a);
+    if (a.splitk > 1) {
+        if (hipMalloc(&a.ws, (size_t)a.splitk * a.M * a.N * sizeof(float)) != hipSuccess) return FGDM_ERR_NOMEM;
+        tmp.ptrs.push_back(a.ws);
+    }
     const int rc = igemm_launch(a, s);
     (void)hipStreamSynchronize(s);   // temporaries are freed on return
     return rc;
@@ -1310,7 +1321,14 @@ int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, i
     if (!a.A0 || !a.Wt || !a.bias || !a.zero) return FGDM_ERR_NOMEM;
     a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.mode = mode;
     a.M = (int)M; a.N = Cout; a.K = K; a.act = act; a.out_kind = OUT_F16; a.out = out; a.ld_out = nout;
-    a.rows_per_sample = Ho * Wo; a.scale = 1.f; a.force_cfg = cfg & 0xff; a.debug = cfg >> 8;
+    a.rows_per_sample = Ho * Wo; a.scale = 1.f; a.force_cfg = cfg & 0xff; a.debug = (cfg >> 8) & 0xff;
+    if (cfg == 0) {
+        a.splitk = igemm_splitk_factor(a);
+        if (a.splitk > 1) {
+            if (hipMalloc(&a.ws, (size_t)a.splitk * a.M * a.N * sizeof(float)) != hipSuccess) return FGDM_ERR_NOMEM;
+            tmp.ptrs.push_back(a.ws);
+        }
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     int rc = FGDM_OK;

@@ -280,6 +280,11 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 63) || (a.C0 & 63) || (a.C1 & 63)) return FGDM_ERR_ARG;
     if (a.act == ACT_GEGLU && (a.N & 63)) return FGDM_ERR_ARG;
     int force = a.force_cfg ? a.force_cfg : g_force_cfg;
+    if (a.splitk > 1) {        // split-K plan made by the caller (igemm_splitk_factor): 128x320 tiles + reduction pass
+        if (!a.ws) return FGDM_ERR_ARG;
+        const int rc = igemm2_launch(a, 2, s);
+        return rc == FGDM_OK ? igemm_splitk_reduce(a, s) : rc;
+    }
     if (force == 0) {
         const bool geglu = a.act == ACT_GEGLU;
         if (!geglu && a.N % 320 == 0) {

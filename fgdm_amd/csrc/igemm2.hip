@@ -10,6 +10,7 @@
 //     channels per register quad: the tile is bounced through wave-private LDS as fp16 and leaves as 16-byte
 //     row-contiguous stores with a 16-byte residual read (the old 2-byte stores cost ~135 us per 84 MB tensor).
 #include "common.h"
+#include <algorithm>
 
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
@@ -49,7 +50,7 @@ constexpr int ROWB = BK * 2;
 
 constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (more samples per tile: global loads)
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT>
 __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, T = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -75,11 +76,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         const int bid = blockIdx.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
+    const int nsplit = SPLIT ? a.splitk : 1;          // split-K lives in its own instantiation (register budget)
+    const int split = SPLIT ? logical % nsplit : 0;
+    const int tile = SPLIT ? logical / nsplit : logical;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
-    const int Ctot = a.C0 + a.C1;
-    const int cpt = Ctot >> 5;      // 32-wide chunks per tap
-    const int nk = a.K >> 5;
+    const int nk_all = a.K >> 5;
+    const int per = (nk_all + nsplit - 1) / nsplit;
+    const int k_begin = split * per;                       // this workgroup's K-step range [k_begin, k_begin + nk)
+    const int nk = max(0, min(per, nk_all - k_begin));
 
     // ---- this wave's load slots.  A slot i covers wave-instruction (wave + i*NW) of the A tile (16 rows x 64 B);
     // B slot likewise; a surplus B slot repeats the last instruction (same bytes to the same LDS address: harmless)
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            glds16((a.debug & 8) ? a.zero : a.Wt + (size_t)b_off[i] + ((size_t)kt << 5), base + b_lds[i]);
+            glds16((a.debug & 8) ? a.zero : a.Wt + (size_t)b_off[i] + ((size_t)(k_begin + kt) << 5), base + b_lds[i]);
     };
 
     // accumulators, TRANSPOSED: acc[nj][mi] = W-tile(nj) x X-tile(mi)^T ; row = channel, lane column = pixel
@@ -159,7 +164,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     for (int ks = 0; ks < 2; ++ks) koff[ks] = lrow * ROWB + (((ks * 2 + lh) ^ swz) << 4);
 
     // ---- prologue: STAGES-1 stages in flight
-    int tap = 0, cc = 0;      // tap index, channel offset of the next stage to issue
+    int tap = 0, cc = k_begin << 5;      // tap index, channel offset of the next stage to issue
+    if (CONV) { const int q = k_begin >> 1; tap = q % 9; cc = (q / 9) * 64 + (k_begin & 1) * 32; }
     auto advance = [&]() {
         if (!CONV) { cc += 32; return; }
         if (cc & 32) {                       // second half of the 64-chunk done: next tap (or next chunk)
@@ -229,6 +235,23 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
     }
 
+    if constexpr (SPLIT) {  // split-K: raw fp32 partial tile -> ws[split][row][col]; igemm_splitk_reduce finishes the job
+        float* wsp = a.ws + (size_t)split * a.M * a.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = m0 + wm * TM + i * 32 + lrow;
+            if (row >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wn * TN + j * 32 + 8 * g + 4 * lh;
+                    f32x4 pk = {acc[j][i][g * 4], acc[j][i][g * 4 + 1], acc[j][i][g * 4 + 2], acc[j][i][g * 4 + 3]};
+                    *(f32x4*)(wsp + (size_t)row * a.N + col) = pk;
+                }
+        }
+        return;
+    } else {
     if (a.debug & 4) {      // ablation: keep the accumulators alive but skip the whole epilogue
         float sink = 0.f;
 #pragma unroll
@@ -348,22 +371,23 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
         }
     }
+    }   // !SPLIT
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false>
 int launch2(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4;      // + staged bias and emb rows
     static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU>;
+    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(WM * WN * 64), smem, s, a);
+    hipLaunchKernelGGL(k, dim3(ntm * ntn * (SPLIT ? a.splitk : 1)), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU>
@@ -372,7 +396,50 @@ int launch2m(const IgemmArgs& a, hipStream_t s) {
                                : launch2<BM, BN, WM, WN, STAGES, true, GEGLU>(a, s);
 }
 
+// out[m][n] = ((sum_s ws[s][m][n]) + bias + emb -> act) * scale + resid, fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a) {
+    const size_t total4 = (size_t)a.M * a.N / 4, plane = (size_t)a.M * a.N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t e0 = i * 4;
+        const int row = (int)(e0 / a.N), col = (int)(e0 - (size_t)row * a.N);
+        f32x4 v = *(const f32x4*)(a.ws + e0);
+        for (int s = 1; s < a.splitk; ++s) {
+            const f32x4 u = *(const f32x4*)(a.ws + (size_t)s * plane + e0);
+            v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+        }
+        h4 r = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+        if (a.resid) r = *(const h4*)(a.resid + (size_t)row * a.ld_res + col);
+        h4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + (a.bias ? a.bias[col + e] : 0.f);
+            if (a.rowvec) x += a.rowvec[(size_t)(row / a.rows_per_sample) * a.rv_stride + col + e];
+            if (a.act == ACT_SILU) x = silu_f(x);
+            else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
+            o[e] = (half_t)(x * a.scale + (float)r[e]);
+        }
+        *(h4*)((half_t*)a.out + (size_t)row * a.ld_out + col) = o;
+    }
+}
+
 }  // namespace
+
+// Split K when a layer cannot fill the chip with 128-row tiles and has a long contraction (the 8x8-latent level).
+int igemm_splitk_factor(const IgemmArgs& a) {
+    if (a.force_cfg || a.act == ACT_GEGLU || a.out_kind != OUT_F16 || a.N % 320 || (a.K & 31)) return 1;
+    const long b128 = (long)((a.M + 127) / 128) * (a.N / 320);
+    if (b128 >= 96) return 1;
+    int s = (int)std::min<long>(8, (256 + b128 - 1) / b128);
+    const int nk = a.K >> 5;
+    while (s > 1 && nk / s < 24) --s;
+    return s;
+}
+int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
+    const size_t total4 = (size_t)a.M * a.N / 4;
+    const int grid = (int)std::min<size_t>(2048, (total4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}
 
 // cfg: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320     (all: 8 waves, 4-stage ring)
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
@@ -381,10 +448,15 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
     const bool g = a.act == ACT_GEGLU;
     if (g && bn != 256) return FGDM_ERR_ARG;
+    if (a.splitk > 1 && cfg != 2) return FGDM_ERR_ARG;
     switch (cfg) {
         case 0: return launch2m<256, 320, 4, 2, 4, false>(a, s);
         case 1: return g ? launch2m<256, 256, 4, 2, 4, true>(a, s) : launch2m<256, 256, 4, 2, 4, false>(a, s);
-        case 2: return launch2m<128, 320, 4, 2, 4, false>(a, s);
+        case 2:
+            if (a.splitk > 1)
+                return a.mode == IG_LINEAR ? launch2<128, 320, 4, 2, 4, false, false, true>(a, s)
+                                           : launch2<128, 320, 4, 2, 4, true, false, true>(a, s);
+            return launch2m<128, 320, 4, 2, 4, false>(a, s);
         default: return FGDM_ERR_ARG;
     }
 }
