@@ -44,7 +44,7 @@ SIGNATURES = {
     'fgdm_load_tensor': (_i, [_p, C.c_char_p, _p, _i, C.POINTER(_i64), _i]),
     'fgdm_finalize_weights': (_i, [_p]),
     'fgdm_set_hint': (_i, [_p, _i, _p, _i, _i, _i, _p]),
-    'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     'fgdm_controlnet': (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p, _i64, _p]),
     'fgdm_ddim_step': (_i, [_p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i64, _p]),
     'fgdm_plms_combine': (_i, [_p, _p, _p, _p, _i, _p, _i64, _p]),

@@ -116,7 +116,8 @@ int add_f16(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s
 }
 
 // y[b] = [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half)   (util.py:160-180); rows >= B are zero
-__global__ void k_timestep_embed(const int64_t* __restrict__ t, half_t* __restrict__ y, int B, int dim, int rows_pad) {
+__global__ void k_timestep_embed(const int64_t* __restrict__ t, const float* __restrict__ tf, half_t* __restrict__ y,
+                                 int B, int dim, int rows_pad) {
     const int half = dim / 2;
     const size_t n = (size_t)rows_pad * dim;
     EW_LOOP(i, n) {
@@ -125,14 +126,14 @@ __global__ void k_timestep_embed(const int64_t* __restrict__ t, half_t* __restri
         if (b < B) {
             const int k = j < half ? j : j - half;
             const float f = expf(-9.210340371976184f * (float)k / (float)half);
-            const float arg = (float)t[b] * f;
+            const float arg = (tf ? tf[b] : (float)t[b]) * f;      // "These may be fractional" (util.py:165): DPM-Solver
             v = j < half ? cosf(arg) : sinf(arg);
         }
         y[i] = (half_t)v;
     }
 }
-int timestep_embed(const int64_t* t, half_t* y, int B, int dim, int rows_pad, hipStream_t s) {
-    hipLaunchKernelGGL(k_timestep_embed, dim3(ew_grid((size_t)rows_pad * dim)), dim3(EW_BLOCK), 0, s, t, y, B, dim, rows_pad);
+int timestep_embed(const int64_t* t, const float* tf, half_t* y, int B, int dim, int rows_pad, hipStream_t s) {
+    hipLaunchKernelGGL(k_timestep_embed, dim3(ew_grid((size_t)rows_pad * dim)), dim3(EW_BLOCK), 0, s, t, tf, y, B, dim, rows_pad);
     return LAUNCH_OK();
 }
 

@@ -723,11 +723,11 @@ struct fgdm_engine {
     }
 
     // timestep_embedding -> time_embed -> SiLU -> all emb_layers (util.py:160-180; openaimodel.py:537-542,827-828,290)
-    int embed(Net& n, const int64_t* t, int B, float** emb_all) {
+    int embed(Net& n, const int64_t* t, const float* tf, int B, float** emb_all) {
         const int mc = cfg.model_channels;
         Tensor te = talloc(1, 1, B, mc), e1, e2;
         if (!te.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        if (timestep_embed(t, te.p, B, mc, B, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "timestep_embed");
+        if (timestep_embed(t, tf, te.p, B, mc, B, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "timestep_embed");
         { Epi e; e.act = ACT_SILU; e.rps = 1; CHK(linear(n.time0, te, e, &e1)); }
         { Epi e; e.act = ACT_SILU; e.rps = 1; CHK(linear(n.time2, e1, e, &e2)); }   // = SiLU(emb): the only use of emb
         *emb_all = (float*)arena.alloc((size_t)B * n.emb_total * sizeof(float));
@@ -780,14 +780,14 @@ struct fgdm_engine {
     // ControlNet.forward (cldm.py:792-813).  fused = true: every zero-conv output is scaled and ADDED in place into
     // the UNet's skip tensor hs[i] / h_mid (cldm.py:40,46 + :846), so control residuals never hit HBM separately.
     // fused = false: raw residuals are written as fp32 NCHW into out32 (test entry).
-    int controlnet_fwd(Net& n, const Tensor& x4, const int64_t* t, const Tensor& ctx16, const float* scales,
+    int controlnet_fwd(Net& n, const Tensor& x4, const int64_t* t, const float* tf, const Tensor& ctx16, const float* scales,
                        std::vector<Tensor>* hs, Tensor* h_mid, bool only_mid, float* out32, int64_t out_cap) {
         const int B = x4.B;
         if (!n.guided.p) return fail(FGDM_ERR_STATE, "fgdm_set_hint has not been called for this ControlNet");
         if (!(n.guided.B == B || 2 * n.guided.B == B) || n.guided.H != x4.H || n.guided.W != x4.W)
             return fail(FGDM_ERR_ARG, "cached hint does not match the batch / latent size");
         float* emb = nullptr;
-        CHK(embed(n, t, B, &emb));
+        CHK(embed(n, t, tf, B, &emb));
         EmbCtx ec{emb, n.emb_total};
         Tensor h;
         int64_t off = 0;
@@ -837,8 +837,8 @@ struct fgdm_engine {
         return FGDM_OK;
     }
 
-    int apply_model(const float* x, const int64_t* t, const float* ctx, const float* pcond, const float* scales,
-                    int B, int H, int W, int flags, float* eps_out) {
+    int apply_model(const float* x, const int64_t* t, const float* tf, const float* ctx, const float* pcond,
+                    const float* scales, int B, int H, int W, int flags, float* eps_out) {
         if (!finalized) return fail(FGDM_ERR_STATE, "weights not finalized");
         if (B <= 0 || H <= 0 || W <= 0) return fail(FGDM_ERR_ARG, "bad shape");
         Net& n = unet;
@@ -848,7 +848,7 @@ struct fgdm_engine {
         if (nchw_f32_to_nhwc_f16(x, x4.p, B, 4, HW, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
         if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
         float* emb = nullptr;
-        CHK(embed(n, t, B, &emb));
+        CHK(embed(n, t, tf, B, &emb));
         EmbCtx ec{emb, n.emb_total};
 
         const bool use_adapter = n.has_adapter && !(flags & FGDM_FLAG_USE_ORIGINAL);
@@ -885,7 +885,7 @@ struct fgdm_engine {
         // ---- ControlNets: residuals accumulate in place into hs / hm (cldm.py:40,46,846)
         if (!cns.empty() && !(flags & FGDM_FLAG_NO_CONTROL)) {
             for (size_t c = 0; c < cns.size(); ++c)
-                CHK(controlnet_fwd(cns[c], x4, t, ctx16, scales ? scales + 13 * c : nullptr, &hs, &hm,
+                CHK(controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, &hs, &hm,
                                    (flags & FGDM_FLAG_ONLY_MID_CONTROL) != 0, nullptr, 0));
         }
         // ---- decoder (openaimodel.py:868-870): virtual concat [h, skip]
@@ -1116,11 +1116,12 @@ int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int 
     return e->set_hint(cn, hint, B, Hh, Wh);
 }
 
-int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* ctx, const float* pcond,
-                     const float* control_scales, int B, int H, int W, int flags, float* eps_out, void* stream) {
-    if (!e || !x || !t || !ctx || !eps_out) return FGDM_ERR_ARG;
+int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* t_float, const float* ctx,
+                     const float* pcond, const float* control_scales, int B, int H, int W, int flags, float* eps_out,
+                     void* stream) {
+    if (!e || !x || (!t && !t_float) || !ctx || !eps_out) return FGDM_ERR_ARG;
     e->s = as_stream(stream);
-    return e->apply_model(x, t, ctx, pcond, control_scales, B, H, W, flags, eps_out);
+    return e->apply_model(x, t, t_float, ctx, pcond, control_scales, B, H, W, flags, eps_out);
 }
 
 int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, const float* ctx, int B, int H, int W,
@@ -1133,7 +1134,7 @@ int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, co
     if (!x4.p || !ctx16.p) return e->fail(FGDM_ERR_NOMEM, "workspace");
     if (nchw_f32_to_nhwc_f16(x, x4.p, B, 4, H * W, 4, e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "layout kernel");
     if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "convert kernel");
-    const int rc = e->controlnet_fwd(e->cns[cn], x4, t, ctx16, nullptr, nullptr, nullptr, false, out, out_capacity_floats);
+    const int rc = e->controlnet_fwd(e->cns[cn], x4, t, nullptr, ctx16, nullptr, nullptr, nullptr, false, out, out_capacity_floats);
     e->tfree(x4); e->tfree(ctx16);
     return rc;
 }
@@ -1195,7 +1196,7 @@ int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* u
         const int index = S - 1 - i;   // reversed walk (ddim.py:137,148)
         HIP_TRY(hipMemcpyAsync(x2, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (cfg_on) HIP_TRY(hipMemcpyAsync(x2 + n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        rc = e->apply_model(x2, tdev + (size_t)index * Bm, c2, nullptr, control_scales, Bm, H, W, flags, eps);
+        rc = e->apply_model(x2, tdev + (size_t)index * Bm, nullptr, c2, nullptr, control_scales, Bm, H, W, flags, eps);
         if (rc != FGDM_OK) break;
         rc = ddim_step(x, cfg_on ? eps + n : eps, cfg_on ? eps : nullptr, cfg_scale, alphas[index], alphas_prev[index], 0.f,
                        sqrt_one_minus_alphas[index], nullptr, x, nullptr, nullptr, n, s);

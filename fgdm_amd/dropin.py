@@ -19,6 +19,7 @@ from . import models, samplers
 _MAP = {
     'ldm.models.diffusion.ddim': {'DDIMSampler': samplers.DDIMSampler},
     'ldm.models.diffusion.plms': {'PLMSSampler': samplers.PLMSSampler},
+    'ldm.models.diffusion.dpm_solver': {'DPMSolverSampler': samplers.DPMSolverSampler},
     'ldm.models.diffusion.ddpm': {'LatentDiffusion': models.LatentDiffusion, 'DiffusionWrapper': models.DiffusionWrapper},
     'controlnet.cldm.ddim_hacked': {'DDIMSampler': samplers.ControlDDIMSampler},
     'controlnet.cldm.cldm': {'ControlLDM': models.ControlLDM},

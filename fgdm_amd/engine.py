@@ -154,7 +154,11 @@ class Engine:
 
     def apply_model(self, x, t, ctx, control_scales=None, flags=0, pcond=None, out=None):
         x = x.to(self.device, torch.float32).contiguous()
-        t = t.to(self.device, torch.int64).contiguous()
+        t_int = t_flt = None
+        if t.is_floating_point():        # fractional timesteps (DPM-Solver)
+            t_flt = t.to(self.device, torch.float32).contiguous()
+        else:
+            t_int = t.to(self.device, torch.int64).contiguous()
         ctx = ctx.to(self.device, torch.float32).contiguous()
         B, Cc, H, W = x.shape
         assert Cc == 4 and ctx.shape[0] == B and ctx.shape[1] == 77 and t.shape[0] == B
@@ -169,8 +173,8 @@ class Engine:
             sc_ptr = C.c_void_p(0)
         if pcond is not None:
             pcond = pcond.to(self.device, torch.float32).contiguous()
-        rc = self.lib.fgdm_apply_model(self.h, _ptr(x), _ptr(t), _ptr(ctx), _ptr(pcond), sc_ptr, B, H, W, flags,
-                                       _ptr(eps), _stream())
+        rc = self.lib.fgdm_apply_model(self.h, _ptr(x), _ptr(t_int), _ptr(t_flt), _ptr(ctx), _ptr(pcond), sc_ptr, B, H, W,
+                                       flags, _ptr(eps), _stream())
         self._check(rc, 'fgdm_apply_model')
         return eps
 

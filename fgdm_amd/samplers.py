@@ -396,6 +396,44 @@ class ControlDDIMSampler(DDIMSampler):
                                      unconditional_guidance_scale=unconditional_guidance_scale,
                                      unconditional_conditioning=unconditional_conditioning)
 
+    def encode(self, x0, c, t_enc, use_original_steps=False, return_intermediates=None,
+               unconditional_guidance_scale=1.0, unconditional_conditioning=None, callback=None):
+        """DDIM inversion x_0 -> x_{t_enc} (ddim_hacked.py:234-279); requires make_schedule() first."""
+        timesteps = np.arange(self.ddpm_num_timesteps) if use_original_steps else self.ddim_timesteps
+        assert t_enc <= timesteps.shape[0]
+        if use_original_steps:
+            a_next = self.alphas_cumprod[:t_enc].detach().cpu().numpy().astype(np.float32)
+            a_cur = self.alphas_cumprod_prev[:t_enc].detach().cpu().numpy().astype(np.float32)
+        else:
+            a_next = np.asarray(self.ddim_alphas[:t_enc], dtype=np.float32)
+            a_cur = np.asarray(self.ddim_alphas_prev[:t_enc], dtype=np.float32)
+        x_next = x0
+        intermediates, inter_steps = [], []
+        for i in range(t_enc):
+            t = torch.full((x0.shape[0],), int(timesteps[i]), device=self.model.device, dtype=torch.long)
+            if unconditional_guidance_scale == 1.:
+                e = self.model.apply_model(x_next, t, c)
+            else:
+                assert unconditional_conditioning is not None
+                e_c, e_u = self._eval_pair(x_next, t, c, unconditional_conditioning, unconditional_guidance_scale)
+                e = _k.cfg_combine(e_c, e_u, unconditional_guidance_scale) if e_u is not None else e_c
+            f32 = np.float32
+            cx = np.sqrt(a_next[i] / a_cur[i])
+            ce = np.sqrt(a_next[i]) * (np.sqrt(f32(1) / a_next[i] - f32(1)) - np.sqrt(f32(1) / a_cur[i] - f32(1)))
+            x_next = _k.axpby(x_next.contiguous(), float(cx), e, float(ce))
+            if return_intermediates and i % (t_enc // return_intermediates) == 0 and i < t_enc - 1:
+                intermediates.append(x_next)
+                inter_steps.append(i)
+            elif return_intermediates and i >= t_enc - 2:
+                intermediates.append(x_next)
+                inter_steps.append(i)
+            if callback:
+                callback(i)
+        out = {'x_encoded': x_next, 'intermediate_steps': inter_steps}
+        if return_intermediates:
+            out.update({'intermediates': intermediates})
+        return x_next, out
+
     @staticmethod
     def _cat_cond(uc, c):
         """One 2B batch is possible when both branches carry the same hint tensors (guess_mode=False)."""
@@ -410,3 +448,123 @@ class ControlDDIMSampler(DDIMSampler):
         if len(uc['c_crossattn']) != len(c['c_crossattn']):
             return None
         return {'c_concat': hc, 'c_crossattn': [torch.cat([a, b]) for a, b in zip(uc['c_crossattn'], c['c_crossattn'])]}
+
+
+# ----------------------------------------------------------------------------------------------- DPM-Solver++
+class _DiscreteVPSchedule:
+    """NoiseScheduleVP('discrete', alphas_cumprod=...) of ldm/models/diffusion/dpm_solver/dpm_solver.py:98-160:
+    log alpha_t is the piecewise-linear interpolation of 0.5 log(alphas_cumprod) over t_k = k/N, k = 1..N (T = 1).
+    Host-side float32 scalars, like the reference's float32 tensors."""
+
+    def __init__(self, alphas_cumprod):
+        ac = np.asarray(alphas_cumprod, dtype=np.float32)
+        self.log_alpha = (np.float32(0.5) * np.log(ac)).astype(np.float32)
+        self.total_N = len(ac)
+        self.T = 1.0
+        self.t_array = np.linspace(0., 1., self.total_N + 1, dtype=np.float32)[1:]
+
+    def marginal_log_mean_coeff(self, t):
+        """interpolate_fn (dpm_solver.py:1132-1171) for one scalar: linear between keypoints, linear extrapolation."""
+        t = np.float32(t)
+        xp, yp = self.t_array, self.log_alpha
+        K = len(xp)
+        idx = int(np.searchsorted(xp, t, side='left'))        # number of keypoints strictly below t
+        if idx == 0:
+            i0 = 0
+        elif idx >= K:
+            i0 = K - 2
+        else:
+            i0 = idx - 1
+        x0, x1, y0, y1 = xp[i0], xp[i0 + 1], yp[i0], yp[i0 + 1]
+        return np.float32(y0 + (t - x0) * (y1 - y0) / (x1 - x0))
+
+    def marginal_alpha(self, t):
+        return np.float32(np.exp(self.marginal_log_mean_coeff(t)))
+
+    def marginal_std(self, t):
+        return np.float32(np.sqrt(np.float32(1.) - np.exp(np.float32(2.) * self.marginal_log_mean_coeff(t))))
+
+    def marginal_lambda(self, t):
+        lm = self.marginal_log_mean_coeff(t)
+        return np.float32(lm - np.float32(0.5) * np.log(np.float32(1.) - np.exp(np.float32(2.) * lm)))
+
+
+class DPMSolverSampler:
+    """ldm/models/diffusion/dpm_solver/sampler.py:8-82: DPM-Solver++ (data prediction), multistep order 2,
+    time_uniform steps from T = 1 to 1/N, lower_order_final, classifier-free guidance as one 2B batch.
+    The model is evaluated at FRACTIONAL timesteps (t - 1/N) * 1000 (dpm_solver.py:278-287)."""
+
+    def __init__(self, model, **kwargs):
+        self.model = model
+        self.alphas_cumprod = torch.as_tensor(model.alphas_cumprod).clone().detach().to(torch.float32).to(model.device)
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
+               unconditional_conditioning=None, **kwargs):
+        if conditioning is not None:
+            cbs = _SamplerBase._batch_of(conditioning)
+            if cbs != batch_size:
+                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        device = self.model.betas.device
+        x = _randn(size, device) if x_T is None else x_T.to(device, torch.float32)
+        ns = _DiscreteVPSchedule(self.alphas_cumprod.detach().cpu().numpy())
+        steps, order = S, 2
+        assert steps >= order
+        ts = np.linspace(ns.T, 1. / ns.total_N, steps + 1, dtype=np.float32)       # get_time_steps('time_uniform')
+        scale, uc = unconditional_guidance_scale, unconditional_conditioning
+
+        def data_prediction(xx, t):
+            # model_wrapper (classifier-free, dpm_solver.py:321-343) + data_prediction_fn (:386-399)
+            t_in = torch.full((xx.shape[0],), float((np.float32(t) - np.float32(1. / ns.total_N)) * np.float32(1000.)),
+                              device=xx.device, dtype=torch.float32)
+            if scale == 1. or uc is None:
+                e = self.model.apply_model(xx, t_in, conditioning)
+            else:
+                out = self.model.apply_model(torch.cat([xx] * 2), torch.cat([t_in] * 2), torch.cat([uc, conditioning]))
+                e_u, e_c = out.chunk(2)
+                e = _k.cfg_combine(e_c.contiguous(), e_u.contiguous(), scale)
+            a, sg = ns.marginal_alpha(t), ns.marginal_std(t)
+            return _k.axpby(xx.contiguous(), float(np.float32(1.) / a), e, float(-sg / a))     # (x - sigma eps) / alpha
+
+        def first_update(xx, s, t, m_s):                         # dpm_solver.py:504-528 (predict_x0 branch)
+            h = ns.marginal_lambda(t) - ns.marginal_lambda(s)
+            c1 = ns.marginal_std(t) / ns.marginal_std(s)
+            c2 = ns.marginal_alpha(t) * np.float32(np.expm1(-h))
+            return _k.axpby(xx, float(c1), m_s, float(-c2))
+
+        def second_update(xx, m_prev, t_prev, t):               # dpm_solver.py:755-789 ('dpm_solver' type, predict_x0)
+            (m1, m0), (t1, t0) = m_prev, t_prev
+            l1, l0, lt = ns.marginal_lambda(t1), ns.marginal_lambda(t0), ns.marginal_lambda(t)
+            h0, h = l0 - l1, lt - l0
+            r0 = h0 / h
+            c1 = ns.marginal_std(t) / ns.marginal_std(t0)
+            c2 = ns.marginal_alpha(t) * (np.float32(np.exp(-h)) - np.float32(1.))
+            # x_t = c1 x - c2 m0 - 0.5 c2 (m0 - m1) / r0
+            y = _k.axpby(xx, float(c1), m0, float(-c2 - np.float32(0.5) * c2 / r0))
+            return _k.axpby(y, 1.0, m1, float(np.float32(0.5) * c2 / r0))
+
+        m_prev = [data_prediction(x, ts[0])]
+        t_prev = [ts[0]]
+        x = first_update(x, t_prev[-1], ts[1], m_prev[-1])      # init_order = 1
+        m_prev.append(data_prediction(x, ts[1]))
+        t_prev.append(ts[1])
+        for step in range(order, steps + 1):
+            t = ts[step]
+            step_order = min(order, steps + 1 - step) if steps < 15 else order      # lower_order_final
+            if step_order == 1:
+                x = first_update(x, t_prev[-1], t, m_prev[-1])
+            else:
+                x = second_update(x, m_prev, t_prev, t)
+            t_prev = [t_prev[1], t]
+            m_prev = [m_prev[1], m_prev[1]]
+            if step < steps:
+                m_prev[-1] = data_prediction(x, t)
+            if callback:
+                callback(step)
+        return x.to(device), None

@@ -71,9 +71,11 @@ int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int 
  * ControlLDM.apply_model (controlnet/cldm/cldm.py:836-849) using the hints cached by fgdm_set_hint:
  * eps = UNet(x, t, ctx, control = sum_k scales_k * ControlNet_k(x, hint_k, t, ctx)).
  * control_scales: n_controlnets * 13 floats (cldm.py:823) or NULL for 1.0.  pcond: optional adapter input
- * (openaimodel.py:838-841) fp32 NCHW or NULL (= x). */
-int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* ctx, const float* pcond,
-                     const float* control_scales, int B, int H, int W, int flags, float* eps_out, void* stream);
+ * (openaimodel.py:838-841) fp32 NCHW or NULL (= x).  Timesteps: int64 `t`, or fractional fp32 `t_float` when non-NULL
+ * (timestep_embedding accepts fractional t, util.py:165; DPM-Solver feeds (t_continuous - 1/N) * 1000). */
+int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* t_float, const float* ctx,
+                     const float* pcond, const float* control_scales, int B, int H, int W, int flags, float* eps_out,
+                     void* stream);
 
 /* ControlNet.forward alone (cldm.py:792-813): the 13 residual tensors as fp32 NCHW, written back-to-back into
  * `out` in the order the reference returns them.  Test/inspection entry; apply_model never materialises them. */

@@ -155,3 +155,22 @@ def test_pipelined_and_two_stage_kernels_both_match_oracle(small_engine):
     assert report('auto tiles (pipelined kernels) vs oracle, 8 rows 64x64', relerr(auto[:B], want), NET_TOL) < NET_TOL
     assert report('forced 2-stage kernel vs oracle, 8 rows 64x64', relerr(forced[:B], want), NET_TOL) < NET_TOL
     assert report('auto vs forced tiles', relerr(auto, forced), NET_TOL) < NET_TOL
+
+
+def test_fractional_timesteps(small_engine):
+    """DPM-Solver evaluates the network at fractional t: float timesteps must equal the int path at integers and
+    follow the oracle's timestep_embedding in between."""
+    from fgdm_amd import _lib
+    from common import params
+    from oracle import arch, nn as onn
+    x = torch.from_numpy(synth.latents(2, 16, 16, seed=31))
+    ctx = torch.from_numpy(synth.context(2, seed=32))
+    f = _lib.FLAG_NO_CONTROL
+    a = small_engine.apply_model(x, torch.tensor([500, 37]), ctx, flags=f).cpu()
+    b = small_engine.apply_model(x, torch.tensor([500.0, 37.0]), ctx, flags=f).cpu()
+    assert torch.equal(a, b)
+    tf = torch.tensor([949.05, 0.5])
+    got = small_engine.apply_model(x, tf, ctx, flags=f).cpu()
+    p = params(arch.unet_param_shapes(gi.SMALL_CFG, adapter=False), 'small.')
+    want = onn.unet_forward(p, gi.SMALL_CFG, x, tf, ctx, prefix='small.')
+    assert report('UNet at fractional timesteps vs oracle', relerr(got, want), NET_TOL) < NET_TOL

@@ -90,3 +90,19 @@ def test_controlnet_sampler_over_engine_vs_oracle():
     assert report('drop-in ControlLDM + ControlDDIMSampler, 4 steps CFG 9 vs oracle', relerr(out.cpu(), want), 1e-2) < 1e-2
     assert len(inter['x_inter']) == 3
     model.engine.close()
+
+
+def test_dpm_solver_and_encode_on_device():
+    g = gold('samplers2')
+    x_T, c, uc = _cuda(gi.get('samp/x_T'), gi.get('samp/c'), gi.get('samp/uc'))
+    for S, scale in ((20, 7.5), (10, 7.5), (12, 1.0)):
+        m = AnalyticLDM('cuda')
+        out, _ = samplers.DPMSolverSampler(m).sample(S, 2, (4, 8, 8), conditioning=c, x_T=x_T, verbose=False,
+                                                     unconditional_guidance_scale=scale, unconditional_conditioning=uc)
+        assert report(f'DPMSolverSampler S{S} scale {scale} (HIP kernels) vs reference',
+                      relerr(out.cpu(), g[f'dpm_S{S}_s{scale}']), 5e-5) < 5e-5
+    m = AnalyticLDM('cuda')
+    smp = samplers.ControlDDIMSampler(m)
+    smp.make_schedule(20, ddim_eta=0.0, verbose=False)
+    enc, _ = smp.encode(gi.get('samp/x0').cuda(), c, 12, unconditional_guidance_scale=5.0, unconditional_conditioning=uc)
+    assert report('DDIM encode (inversion) 12 steps vs reference', relerr(enc.cpu(), g['encode_cfg']), STOL) < STOL

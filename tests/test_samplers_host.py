@@ -162,3 +162,27 @@ def test_dropin_import_paths():
     assert DDIMSampler is samplers.DDIMSampler and PLMSSampler is samplers.PLMSSampler
     assert CNSampler is samplers.ControlDDIMSampler and LatentDiffusion is models.LatentDiffusion
     assert ControlLDM is models.ControlLDM
+
+
+def test_dpm_solver_and_ddim_encode(stubs):
+    """DPM-Solver++ 2M (fractional timesteps, lower_order_final below 15 steps) and DDIM inversion vs the reference."""
+    g = gold('samplers2')
+    x_T, c, uc = gi.get('samp/x_T'), gi.get('samp/c'), gi.get('samp/uc')
+    for S, scale in ((20, 7.5), (10, 7.5), (12, 1.0)):
+        m = AnalyticLDM()
+        out, _ = samplers.DPMSolverSampler(m).sample(S, 2, (4, 8, 8), conditioning=c, x_T=x_T, verbose=False,
+                                                     unconditional_guidance_scale=scale, unconditional_conditioning=uc)
+        assert relerr(out, g[f'dpm_S{S}_s{scale}']) < 2e-5, (S, scale)
+        assert m.calls == int(g[f'dpm_S{S}_s{scale}_calls'][0]) == S
+    m = AnalyticLDM()
+    smp = samplers.ControlDDIMSampler(m)
+    smp.make_schedule(20, ddim_eta=0.0, verbose=False)
+    x0 = gi.get('samp/x0')
+    enc, info = smp.encode(x0, c, 12, unconditional_guidance_scale=5.0, unconditional_conditioning=uc,
+                           return_intermediates=3)
+    assert relerr(enc, g['encode_cfg']) < STOL
+    assert relerr(torch.stack(info['intermediates']), g['encode_cfg_inter']) < STOL
+    assert list(info['intermediate_steps']) == list(g['encode_cfg_steps'])
+    hint = gi.hint(2, 64, 48)
+    enc, _ = smp.encode(x0, {'c_concat': [hint], 'c_crossattn': [c]}, 15)
+    assert relerr(enc, g['encode_plain']) < STOL

@@ -415,6 +415,43 @@ def g_samplers():
     save('samplers', **arrs)
 
 
+def g_samplers2():
+    """DPM-Solver++ (scripts/txt2img.py --dpm_solver) and DDIM inversion (ddim_hacked.encode) with the analytic model."""
+    import contextlib
+    import io
+    from ldm.models.diffusion.dpm_solver import DPMSolverSampler
+    from controlnet.cldm.ddim_hacked import DDIMSampler as CNSampler
+    arrs = {}
+    shape = (4, 8, 8)
+    x_T, c, uc = gi.get('samp/x_T'), gi.get('samp/c'), gi.get('samp/uc')
+    sink = io.StringIO()
+    with torch.no_grad(), contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+        for S, scale in ((20, 7.5), (10, 7.5), (12, 1.0)):
+            fm = FakeModel(analytic_eps)
+            smp = _cpu_sampler(DPMSolverSampler)(fm)
+            out, _ = smp.sample(S, 2, shape, conditioning=c, x_T=x_T, verbose=False,
+                                unconditional_guidance_scale=scale, unconditional_conditioning=uc)
+            arrs[f'dpm_S{S}_s{scale}'] = out
+            arrs[f'dpm_S{S}_s{scale}_calls'] = np.asarray([fm.calls])
+        fm = FakeModel(analytic_eps)
+        smp = _cpu_sampler(CNSampler)(fm)
+        smp.make_schedule(20, ddim_eta=0.0, verbose=False)
+        hint = gi.hint(2, 64, 48)
+        cond = {'c_concat': [hint], 'c_crossattn': [c]}
+        ucond = {'c_concat': [hint], 'c_crossattn': [uc]}
+        x0 = gi.get('samp/x0')
+        # the reference's CFG branch of encode() concatenates the conditionings with torch.cat, which only works for
+        # tensor conditionings: use tensors for the guided case and dict conds for the unguided one
+        enc, info = smp.encode(x0, c, 12, unconditional_guidance_scale=5.0, unconditional_conditioning=uc,
+                               return_intermediates=3)
+        arrs['encode_cfg'] = enc
+        arrs['encode_cfg_inter'] = torch.stack(info['intermediates'])
+        arrs['encode_cfg_steps'] = np.asarray(info['intermediate_steps'])
+        enc, _ = smp.encode(x0, cond, 15)
+        arrs['encode_plain'] = enc
+    save('samplers2', **arrs)
+
+
 def g_sampler_unet():
     """End-to-end compounding: reference DDIMSampler driving the reference reduced UNet (SMALL_CFG) at 16x16."""
     import contextlib
@@ -438,7 +475,7 @@ def g_sampler_unet():
 
 ALL = dict(schedule=g_schedule, ddpm_schedule=g_ddpm_schedule, param_keys=g_param_keys, ops=g_ops,
            unet_full=g_unet_full, controlnet_full=g_controlnet_full, small_nets=g_small_nets,
-           samplers=g_samplers, sampler_unet=g_sampler_unet)
+           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet)
 
 
 def main():
