@@ -424,15 +424,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a) {
 
 }  // namespace
 
-// Split K when a layer cannot fill the chip with 128-row tiles and has a long contraction (the 8x8-latent level).
+// Split K for the long-contraction layers of the coarsest latent level (<= 8x8 positions per sample: M = 64 B rows
+// cannot fill the chip with 128-row tiles).  The decision depends ONLY on the per-sample geometry and K -- never on
+// the batch size -- so a sample's result stays bit-identical whatever batch (or rank shard) it is evaluated in.
 int igemm_splitk_factor(const IgemmArgs& a) {
     if (a.force_cfg || a.act == ACT_GEGLU || a.out_kind != OUT_F16 || a.N % 320 || (a.K & 31)) return 1;
-    const long b128 = (long)((a.M + 127) / 128) * (a.N / 320);
-    if (b128 >= 96) return 1;
-    int s = (int)std::min<long>(8, (256 + b128 - 1) / b128);
     const int nk = a.K >> 5;
-    while (s > 1 && nk / s < 24) --s;
-    return s;
+    return (a.rows_per_sample <= 64 && nk >= 96) ? 4 : 1;
 }
 int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
     const size_t total4 = (size_t)a.M * a.N / 4;

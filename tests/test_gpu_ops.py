@@ -60,8 +60,8 @@ CONV_CASES = [
     (2, 16, 16, 320, 0, 4, 3, 1, 0, 0, 'N=4 (UNet out conv)'),
     (1, 64, 64, 320, 0, 320, 3, 1, 0, 2, 'full-res latent, relu'),
     (2, 7, 5, 64, 0, 96, 3, 2, 0, 0, 'odd sizes'),
-    (1, 16, 16, 640, 0, 320, 3, 1, 0, 1, 'split-K (M=256, K=5760) silu + rowvec + resid'),
-    (2, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 'split-K decoder concat (M=128, K=23040)'),
+    (3, 8, 8, 640, 0, 320, 3, 1, 0, 1, 'split-K (8x8, K=5760) silu + rowvec + resid'),
+    (2, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 'split-K decoder concat (8x8, K=23040)'),
 ]
 
 
