@@ -30,6 +30,11 @@ TFLOP_PER_IMAGE = 107.20  # BASELINE.md section 3, config C3 (hint block once pe
 PEAK_TFLOPS = 2500.0      # dense fp16 MFMA, MI355X_MICROARCH.md
 
 
+def log(msg):
+    """progress on stderr (stdout carries exactly one JSON line)"""
+    print(f'[bench] {msg}', file=sys.stderr, flush=True)
+
+
 def build_model(rank, world):
     """ControlLDM mirror (reference API) over the HIP engine; frozen weights are generated on rank 0 only and
     shipped with ONE RCCL broadcast of a flat fp32 buffer (fgdm_amd/dist.py)."""
@@ -53,8 +58,14 @@ def cpu_baseline():
     from oracle import arch, nn as onn
     cfg = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1),
                num_res_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
-    cores = os.cpu_count() or 1
+    # host cores this process may use: the GPU box gives a CPU share of 16 per GPU whatever os.cpu_count() says
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get('FGDM_CPU_BASELINE_THREADS', '16'))))
     torch.set_num_threads(cores)
+    log(f'cpu_baseline: oracle ControlNet+UNet CFG pair on {cores} host threads ...')
     p = {}
     for pre, shapes in (('model.diffusion_model.', arch.unet_param_shapes(cfg, adapter=False)),
                         ('control_model.', arch.controlnet_param_shapes(cfg))):
@@ -70,6 +81,7 @@ def cpu_baseline():
             t0 = time.time()
             onn.control_ldm_apply(p, cfg, x, t, ctx, [hint])
             times.append(time.time() - t0)
+            log(f'cpu_baseline: evaluation {i} took {times[-1]:.1f} s')
     sec = float(np.mean(times[1:]))            # first call = warm-up
     return {'value': 1.0 / (DDIM_STEPS * sec), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': f'2 timed CFG-pair evaluations (B=2: uncond+cond) of ControlNet+UNet @64x64, hint 512^2, '
@@ -125,9 +137,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        log(f'weights ready ({n_params / 1e9:.2f} G params, {load_s:.1f} s); warm-up x{a.warmup} ...')
     for _ in range(a.warmup):
         out = one_step()
     barrier()
+    if rank == 0:
+        log(f'timing {a.steps} step(s) of {a.ddim_steps} DDIM steps x {npg} prompts per GPU ...')
     engine.profile_begin()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -142,6 +158,14 @@ def main():
     assert torch.isfinite(out).all(), 'non-finite latents'
 
     if rank == 0:
+        # HBM traffic per launch of the dominant kernel family: measured offline with rocprofv3 PMC passes
+        # (tools/pmc_summary.py -> profiles/pmc_traffic.json); null when no measurement is committed
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            traffic = pj['igemm']['hbm_bytes_per_launch']
+        except Exception:
+            pass
         images = N * a.steps
         value = images / dt
         ig = prof['igemm']
@@ -158,7 +182,9 @@ def main():
                        'prompts_per_gpu': npg, 'ddim_steps': a.ddim_steps, 'cfg_scale': CFG_SCALE,
                        'parallelism': f'prompt-shard x{world}, RCCL weight broadcast only'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, rocprofv3)',
+                         'algorithmic_bytes_per_launch': ig['bytes'] / max(ig['launches'], 1),
                          'kernel': 'igemm_kernel<*> (implicit-GEMM conv3x3/conv1x1/linear family)',
                          'launches': ig['launches'], 'avg_launch_us': ig['ms'] * 1e3 / max(ig['launches'], 1),
                          'algorithmic_tflop_per_launch': ig['work'] / max(ig['launches'], 1) / 1e12},
@@ -171,6 +197,7 @@ def main():
             'weights': {'params': n_params, 'load_s': round(load_s, 2)},
             'workspace': engine.workspace_stats(),
         }
+        log(f'{value:.3f} images/s; igemm {achieved:.0f} TFLOP/s')
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -140,6 +140,7 @@ struct Prof {
     struct Rec { int cls; size_t e0, e1; double w; char tag[56]; };
     std::vector<Rec> recs;
     double work[PC_COUNT] = {0, 0, 0, 0};     // flops (igemm, attention) or bytes (norm, elementwise)
+    double bytes[PC_COUNT] = {0, 0, 0, 0};    // algorithmic HBM bytes (each operand once)
     hipEvent_t get() {
         if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
         return pool[used++];
@@ -561,6 +562,11 @@ struct fgdm_engine {
             if (!a.ws) return fail(FGDM_ERR_NOMEM, "workspace (split-K partials)");
         }
         prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real, tag);
+        if (prof.on) {   // operands once: activations + weights + residual + output
+            const double in_b = 2.0 * ((double)x0.numel() + (x1 ? (double)x1->numel() : 0.0));
+            const double out_b = (double)a.M * nout * (e.out_kind == OUT_F16 || e.out_kind == OUT_F16_T ? 2.0 : 4.0);
+            prof.bytes[PC_IGEMM] += in_b + 2.0 * (double)w.N * w.K + out_b + (e.resid ? 2.0 * (double)a.M * nout : 0.0);
+        }
         const int rc = igemm_launch(a, s);
         prof.end(s);
         if (a.ws) arena.release(a.ws);
@@ -1066,24 +1072,24 @@ int fgdm_profile_begin(fgdm_engine* e) {
     e->prof.on = true;
     e->prof.used = 0;
     e->prof.recs.clear();
-    for (int c = 0; c < PC_COUNT; ++c) e->prof.work[c] = 0;
+    for (int c = 0; c < PC_COUNT; ++c) { e->prof.work[c] = 0; e->prof.bytes[c] = 0; }
     return FGDM_OK;
 }
-// out[class][3] = {device milliseconds, launches, algorithmic work (flops for classes 0/1, bytes for 2/3)};
+// out[class][4] = {device milliseconds, launches, algorithmic work (flops for classes 0/1, bytes for 2/3), algorithmic bytes};
 // classes: 0 implicit-GEMM (conv / linear), 1 attention, 2 GroupNorm + LayerNorm, 3 im2col.  Synchronises the device.
 int fgdm_profile_end(fgdm_engine* e, double* out) {
     if (!e || !out) return FGDM_ERR_ARG;
     e->prof.on = false;
     if (hipDeviceSynchronize() != hipSuccess) return e->fail(FGDM_ERR_HIP, "hipDeviceSynchronize failed");
-    for (int c = 0; c < PC_COUNT * 3; ++c) out[c] = 0;
+    for (int c = 0; c < PC_COUNT * 4; ++c) out[c] = 0;
     for (auto& r : e->prof.recs) {
         if (!r.e1) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->prof.pool[r.e0], e->prof.pool[r.e1]) != hipSuccess) continue;
-        out[r.cls * 3 + 0] += ms;
-        out[r.cls * 3 + 1] += 1;
+        out[r.cls * 4 + 0] += ms;
+        out[r.cls * 4 + 1] += 1;
     }
-    for (int c = 0; c < PC_COUNT; ++c) out[c * 3 + 2] = e->prof.work[c];
+    for (int c = 0; c < PC_COUNT; ++c) { out[c * 4 + 2] = e->prof.work[c]; out[c * 4 + 3] = e->prof.bytes[c]; }
     // optional per-shape dump: FGDM_PROF_DUMP=<path>  ->  "tag <tab> launches <tab> total_ms <tab> work"
     if (const char* path = getenv("FGDM_PROF_DUMP")) {
         std::map<std::string, std::array<double, 3>> agg;

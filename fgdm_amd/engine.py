@@ -204,9 +204,9 @@ class Engine:
 
     def profile_end(self):
         """{class: dict(ms, launches, work)}; work = algorithmic flops (igemm, attention) or bytes (norm, im2col)."""
-        buf = (C.c_double * 12)()
+        buf = (C.c_double * 16)()
         self._check(self.lib.fgdm_profile_end(self.h, buf), 'fgdm_profile_end')
-        return {n: dict(ms=buf[3 * i], launches=int(buf[3 * i + 1]), work=buf[3 * i + 2])
+        return {n: dict(ms=buf[4 * i], launches=int(buf[4 * i + 1]), work=buf[4 * i + 2], bytes=buf[4 * i + 3])
                 for i, n in enumerate(self.PROFILE_CLASSES)}
 
     def workspace_stats(self):

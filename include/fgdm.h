@@ -112,7 +112,7 @@ int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* u
 
 /* Built-in kernel timer (no reference counterpart: the reference only prints wall-clock, scripts/txt2img.py:381-396).
  * Between begin and end every kernel launch is bracketed by HIP events on the launch stream.
- * out: 4 classes x {device ms, launches, algorithmic work}; classes: 0 implicit GEMM (flops), 1 attention (flops),
+ * out: 4 classes x {device ms, launches, algorithmic work, algorithmic HBM bytes (igemm only)}; classes: 0 implicit GEMM (flops), 1 attention (flops),
  * 2 GroupNorm+LayerNorm (bytes), 3 im2col (bytes).  fgdm_profile_end synchronises the device. */
 int fgdm_profile_begin(fgdm_engine* e);
 int fgdm_profile_end(fgdm_engine* e, double* out);
