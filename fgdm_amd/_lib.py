@@ -53,7 +53,7 @@ SIGNATURES = {
     'fgdm_ancestral_step': (_i, [_p, _p, _f, _f, _f, _f, _f, _p, _p, _i64, _p]),
     'fgdm_sample_ddim': (_i, [_p, _p, _p, _p, _f, _i, C.POINTER(_i64), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
                               _p, _i, _i, _i, _i, _p]),
-    'fgdm_profile_begin': (_i, [_p]),
+    'fgdm_profile_begin': (_i, [_p, _i]),
     'fgdm_profile_end': (_i, [_p, C.POINTER(C.c_double)]),
     'fgdm_workspace_stats': (_i, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
     'fgdm_op_conv2d': (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p]),

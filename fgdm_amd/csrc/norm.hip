@@ -60,38 +60,38 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     }
 }
 
-// stats[b][g] = (mean, rstd)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, float inv_count, float eps,
-                                   float* __restrict__ stats) {
-    const int b = blockIdx.x, g = threadIdx.x;
-    if (g >= 32) return;
-    // double accumulation: the E[x^2] - mean^2 form must not lose digits when |mean| >> std
-    double s = 0.0, q = 0.0;
-    for (int c = 0; c < nchunk; ++c) {
-        s += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2];
-        q += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2 + 1];
-    }
-    const double mean = s * inv_count;
-    double var = q * inv_count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[(b * 32 + g) * 2] = (float)mean;
-    stats[(b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x0, int C0,
                                                         const half_t* __restrict__ x1, int C1, int HW,
-                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ partial, int nchunk,
+                                                        float inv_count, float eps,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu,
                                                         half_t* __restrict__ out) {
-    extern __shared__ float sc[];   // scale[C], shift[C]
+    extern __shared__ float sc[];   // scale[C], shift[C], then stats[32][2]
     const int C = C0 + C1, P = C >> 3, cpg = C >> 5;
     const int b = blockIdx.y;
     float* scale = sc;
     float* shift = sc + C;
+    float* stats = sc + 2 * C;
+    // every block reduces the per-chunk partial sums of its sample itself (fixed order, double accumulation:
+    // the E[x^2] - mean^2 form must not lose digits when |mean| >> std) -- no separate finalize launch
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x;
+        double s = 0.0, q = 0.0;
+        for (int c = 0; c < nchunk; ++c) {
+            s += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2];
+            q += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2 + 1];
+        }
+        const double mean = s * inv_count;
+        double var = q * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[g * 2] = (float)mean;
+        stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
         const int g = c / cpg;
-        const float mean = stats[(b * 32 + g) * 2], rstd = stats[(b * 32 + g) * 2 + 1];
+        const float mean = stats[g * 2], rstd = stats[g * 2 + 1];
         const float w = gamma[c] * rstd;
         scale[c] = w;
         shift[c] = beta[c] - mean * w;
@@ -125,18 +125,16 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
     if ((C & 31) || (C0 & 7) || (C1 & 7) || C > 4096 || B <= 0 || HW <= 0) return FGDM_ERR_ARG;
     const int nchunk = (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK;
     float* partial = ws;
-    float* stats = ws + (size_t)B * nchunk * 64;
     const int P = C >> 3, PI = P <= 256 ? 256 / P : 1;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), (size_t)PI * C * 2 * sizeof(float), s, x0, C0, x1,
                        C1, HW, partial);
     const float inv_count = 1.0f / ((float)HW * (float)(C / 32));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, partial, nchunk, inv_count, eps, stats);
     const size_t total = (size_t)HW * (C >> 3);
     int gx = (int)((total + 255) / 256);
     if (gx > 2048 / (B < 8 ? B : 8)) gx = 2048 / (B < 8 ? B : 8);
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), 2 * C * sizeof(float), s, x0, C0, x1, C1, HW,
-                       stats, gamma, beta, silu, out);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), (2 * C + 64) * sizeof(float), s, x0, C0, x1, C1, HW,
+                       partial, nchunk, inv_count, eps, gamma, beta, silu, out);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 

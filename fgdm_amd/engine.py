@@ -199,8 +199,9 @@ class Engine:
     # ------------------------------------------------------------------ built-in kernel timer
     PROFILE_CLASSES = ('igemm', 'attention', 'norm', 'im2col')
 
-    def profile_begin(self):
-        self._check(self.lib.fgdm_profile_begin(self.h), 'fgdm_profile_begin')
+    def profile_begin(self, stride=1):
+        """Bracket every `stride`-th kernel launch with HIP events (1 = every launch)."""
+        self._check(self.lib.fgdm_profile_begin(self.h, int(stride)), 'fgdm_profile_begin')
 
     def profile_end(self):
         """{class: dict(ms, launches, work)}; work = algorithmic flops (igemm, attention) or bytes (norm, im2col)."""

@@ -111,10 +111,11 @@ int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* u
                      int flags, void* stream);
 
 /* Built-in kernel timer (no reference counterpart: the reference only prints wall-clock, scripts/txt2img.py:381-396).
- * Between begin and end every kernel launch is bracketed by HIP events on the launch stream.
+ * Between begin and end every stride-th kernel launch is bracketed by HIP events on the launch stream
+ * (work / bytes / time totals then refer to the bracketed launches only).
  * out: 4 classes x {device ms, launches, algorithmic work, algorithmic HBM bytes (igemm only)}; classes: 0 implicit GEMM (flops), 1 attention (flops),
  * 2 GroupNorm+LayerNorm (bytes), 3 im2col (bytes).  fgdm_profile_end synchronises the device. */
-int fgdm_profile_begin(fgdm_engine* e);
+int fgdm_profile_begin(fgdm_engine* e, int stride /* bracket every stride-th launch; 1 = all */);
 int fgdm_profile_end(fgdm_engine* e, double* out);
 /* Activation workspace: peak bytes in use during the last calls, and bytes reserved from HBM. */
 int fgdm_workspace_stats(fgdm_engine* e, int64_t* peak_bytes, int64_t* reserved_bytes);
