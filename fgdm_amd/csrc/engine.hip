@@ -101,6 +101,7 @@ enum LType { L_CONV, L_RES, L_ATTN, L_DOWN, L_UP };
 struct Layer {
     LType type = L_CONV;
     int cin = 0, cout = 0, heads = 0;
+    bool down = false;                                     // L_RES with AvgPool2d(2) on both branches (TimeAdapter)
     std::string pre;
     GemmW conv;                                            // L_CONV / L_DOWN / L_UP
     NormW gn1, gn2; GemmW c1, c2, skip; int emb_off = 0;   // L_RES
@@ -121,6 +122,7 @@ struct Net {
     NormW out_gn; GemmW out_conv;                          // UNet only
     bool has_adapter = false;                              // UNet only
     GemmW ad_conv_in; std::vector<AdapterBlk> ad_body;
+    bool time_adapter = false; Block tad_body;             // TimeAdapter: time-conditioned ResBlocks (adapter.py:387-417)
     std::vector<GemmW> zero_convs; GemmW mid_out;          // ControlNet only
     std::vector<int> zero_ch;
     GemmW hint_convs[8];
@@ -249,8 +251,9 @@ struct fgdm_engine {
         return false;
     }
     // openaimodel.py:558-718 / cldm.py:640-787
-    void build_net(Net& n, const std::string& prefix, bool control, bool adapter) {
-        n.prefix = prefix; n.control = control; n.has_adapter = adapter;
+    void build_net(Net& n, const std::string& prefix, bool control, int adapter_kind) {
+        const bool adapter = adapter_kind == 1;
+        n.prefix = prefix; n.control = control; n.has_adapter = adapter_kind != 0; n.time_adapter = adapter_kind == 2;
         const int mc = cfg.model_channels, temb = 4 * mc, ctx = cfg.context_dim, heads = cfg.num_heads;
         reg_wb(prefix + "time_embed.0", {temb, mc});
         reg_wb(prefix + "time_embed.2", {temb, temb});
@@ -268,6 +271,20 @@ struct fgdm_engine {
                     reg_wb(b.pre + "block1", {b.oc, b.oc, 3, 3});
                     reg_wb(b.pre + "block2", {b.oc, b.oc, 1, 1});
                     n.ad_body.push_back(b);
+                }
+            reg_wb(ap + "conv_in", {chs[0], cfg.in_channels, 3, 3});
+        }
+        if (n.time_adapter) {   // TimeAdapter(cin, [320,640,1280,1280], nums_rb=2, use_conv=False): openaimodel.py:554
+            static const int chs[4] = {320, 640, 1280, 1280};
+            const std::string ap = prefix + "adapter.";
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    const bool down = (i != 0 && j == 0);
+                    Layer l = mk(L_RES, down ? chs[i - 1] : chs[i], chs[i]);
+                    l.down = down;
+                    l.pre = ap + "body." + std::to_string(i * 2 + j) + ".";
+                    reg_res(l.pre, l.cin, l.cout, temb);
+                    n.tad_body.push_back(l);
                 }
             reg_wb(ap + "conv_in", {chs[0], cfg.in_channels, 3, 3});
         }
@@ -337,10 +354,11 @@ struct fgdm_engine {
         }
         if (cfg.use_adapter && !(cfg.model_channels == 320 && cfg.n_levels == 4 && cfg.num_res_blocks == 2))
             return fail(FGDM_ERR_ARG, "FG-DM adapter requires the SD-v1 topology (openaimodel.py:554-556,855-859)");
-        build_net(unet, "model.diffusion_model.", false, cfg.use_adapter != 0);
+        if (cfg.use_adapter < 0 || cfg.use_adapter > 2) return fail(FGDM_ERR_ARG, "use_adapter: 0 none, 1 Adapter, 2 TimeAdapter");
+        build_net(unet, "model.diffusion_model.", false, cfg.use_adapter);
         cns.resize(cfg.n_controlnets);
         for (int k = 0; k < cfg.n_controlnets; ++k)
-            build_net(cns[k], k == 0 ? std::string("control_model.") : "control_model_" + std::to_string(k) + ".", true, false);
+            build_net(cns[k], k == 0 ? std::string("control_model.") : "control_model_" + std::to_string(k) + ".", true, 0);
         return FGDM_OK;
     }
 
@@ -493,6 +511,7 @@ struct fgdm_engine {
         for (auto& b : n.input) collect(b);
         collect(n.middle);
         for (auto& b : n.output) collect(b);
+        collect(n.tad_body);
         n.emb_total = off;
         CHK(pack_stack(n.emb_all, embs, true));
         for (auto& b : n.input) CHK(pack_block(b));
@@ -501,6 +520,7 @@ struct fgdm_engine {
         if (!n.control) {
             CHK(pack_norm(n.out_gn, n.prefix + "out.0"));
             CHK(pack_conv3(n.out_conv, n.prefix + "out.2"));
+            if (n.time_adapter) CHK(pack_block(n.tad_body));
             if (n.has_adapter) {
                 CHK(pack_conv3(n.ad_conv_in, n.prefix + "adapter.conv_in"));
                 for (auto& b : n.ad_body) {
@@ -635,8 +655,20 @@ struct fgdm_engine {
 
     // ResBlock._forward (openaimodel.py:275-301); x1 = skip tensor of the decoder's channel concat
     int res_fwd(const Layer& l, const Tensor& x, const Tensor* x1, const EmbCtx& ec, Tensor* out) {
-        Tensor g1, h, g2, sk;
+        Tensor g1, h, g2, sk, xp;
         CHK(gnorm(l.gn1, x, x1, 1e-5f, true, &g1));
+        const Tensor* xs = &x;       // the tensor the skip path reads
+        if (l.down) {                // ResBlock(down=True, use_conv=False): AvgPool2d(2) on h and on x (openaimodel.py:276-282)
+            if (x1) return fail(FGDM_ERR_ARG, "down ResBlock with a concatenated input");
+            Tensor gp = talloc(x.B, x.H / 2, x.W / 2, x.C);
+            xp = talloc(x.B, x.H / 2, x.W / 2, x.C);
+            if (!gp.p || !xp.p) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (avgpool2(g1.p, gp.p, x.B, x.H, x.W, x.C, s) != FGDM_OK || avgpool2(x.p, xp.p, x.B, x.H, x.W, x.C, s) != FGDM_OK)
+                return fail(FGDM_ERR_ARG, "avgpool2: latent size must be divisible by 8 for the adapter");
+            tfree(g1);
+            g1 = gp;
+            xs = &xp;
+        }
         Epi e1; e1.rowvec = ec.emb_all + l.emb_off; e1.rv_stride = ec.stride;
         CHK(conv3(l.c1, g1, nullptr, 1, false, e1, &h));
         tfree(g1);
@@ -644,14 +676,15 @@ struct fgdm_engine {
         tfree(h);
         Epi e2;
         if (l.cin != l.cout) {
-            CHK(linear(l.skip, x, Epi{}, &sk, x1));
+            CHK(linear(l.skip, *xs, Epi{}, &sk, x1));
             e2.resid = sk.p; e2.ld_res = sk.C;
         } else {
-            e2.resid = x.p; e2.ld_res = x.C;
+            e2.resid = xs->p; e2.ld_res = xs->C;
         }
         CHK(conv3(l.c2, g2, nullptr, 1, false, e2, out));
         tfree(g2);
         if (sk.p) tfree(sk);
+        if (xp.p) tfree(xp);
         return FGDM_OK;
     }
 
@@ -782,6 +815,22 @@ struct fgdm_engine {
         return FGDM_OK;
     }
 
+    // TimeAdapter.forward (adapter.py:405-417): conv_in, then 8 time-conditioned ResBlocks, a feature every second one
+    int time_adapter_fwd(Net& n, const Tensor& x4, const EmbCtx& ec, Tensor feats[4]) {
+        Tensor cur;
+        CHK(conv3(n.ad_conv_in, x4, nullptr, 1, false, Epi{}, &cur));
+        for (size_t k = 0; k < n.tad_body.size(); ++k) {
+            Tensor y;
+            CHK(res_fwd(n.tad_body[k], cur, nullptr, ec, &y));
+            bool keep = false;
+            for (int f = 0; f < 4; ++f) if (feats[f].p == cur.p) keep = true;
+            if (!keep) tfree(cur);
+            cur = y;
+            if (k % 2 == 1) feats[k / 2] = cur;
+        }
+        return FGDM_OK;
+    }
+
     int ensure_device() {
         if (device_ready) return FGDM_OK;
         if (hipSetDevice(device) != hipSuccess) return fail(FGDM_ERR_HIP, "hipSetDevice failed (no GPU?)");
@@ -872,10 +921,10 @@ struct fgdm_engine {
                 Tensor p4 = talloc(B, H, W, 4);
                 if (!p4.p) return fail(FGDM_ERR_NOMEM, "workspace");
                 if (nchw_f32_to_nhwc_f16(pcond, p4.p, B, 4, HW, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
-                CHK(adapter_fwd(n, p4, fa));
+                CHK(n.time_adapter ? time_adapter_fwd(n, p4, ec, fa) : adapter_fwd(n, p4, fa));
                 tfree(p4);
             } else {
-                CHK(adapter_fwd(n, x4, fa));
+                CHK(n.time_adapter ? time_adapter_fwd(n, x4, ec, fa) : adapter_fwd(n, x4, fa));
             }
         }
         // ---- encoder (openaimodel.py:849-858); the adapter feature is added BEFORE the skip is recorded

@@ -30,7 +30,7 @@ def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, w
         c.attention_resolutions[i] = v
     c.num_heads = cfg['num_heads']
     c.context_dim = cfg['context_dim']
-    c.use_adapter = int(bool(use_adapter))
+    c.use_adapter = 2 if use_adapter in ('time', 2) else int(bool(use_adapter))      # 'time' -> TimeAdapter
     c.n_controlnets = int(n_controlnets)
     c.hint_channels = hint_channels
     c.workspace_bytes = int(workspace_bytes)

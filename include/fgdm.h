@@ -32,7 +32,8 @@ typedef struct fgdm_config {
     int32_t n_attention_resolutions;
     int32_t attention_resolutions[FGDM_MAX_LEVELS];
     int32_t num_heads, context_dim;
-    int32_t use_adapter;       /* 1: FG-DM UNet with the self-prompt Adapter (openaimodel.py:554-556) */
+    int32_t use_adapter;       /* FG-DM self-prompt adapter (openaimodel.py:551-556): 0 none (no_prompting), 1 Adapter,
+                                * 2 TimeAdapter (use_time_adapter=True; ldm/modules/encoders/adapter.py:387-417) */
     int32_t n_controlnets;     /* 0..FGDM_MAX_CONTROLNETS ControlNet twin encoders (cldm.py:545-790) */
     int32_t hint_channels;     /* 3 */
     int64_t workspace_bytes;   /* initial activation slab; 0 = default; grows on demand */

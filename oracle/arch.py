@@ -153,8 +153,18 @@ def adapter_param_shapes(cin=4, channels=ADAPTER_CHANNELS, nums_rb=2, prefix='ad
     return p
 
 
+def time_adapter_param_shapes(cin=4, channels=ADAPTER_CHANNELS, nums_rb=2, temb=1280, prefix='adapter.'):
+    """TimeAdapter (adapter.py:387-403): openaimodel-style ResBlocks, `down=True` on the first block of levels > 0."""
+    p = OrderedDict()
+    for k, (ic, oc, down) in enumerate(adapter_blocks(cin, channels, nums_rb)):
+        _res_params(p, f'{prefix}body.{k}.', ic, oc, temb)
+    p[prefix + 'conv_in.weight'] = (channels[0], cin, 3, 3)
+    p[prefix + 'conv_in.bias'] = (channels[0],)
+    return p
+
+
 def unet_param_shapes(cfg, adapter=True, prefix=''):
-    """State-dict keys -> shapes of the reference UNetModel (with FG-DM adapter)."""
+    """State-dict keys -> shapes of the reference UNetModel (adapter: False | True (Adapter) | 'time' (TimeAdapter))."""
     mc = cfg['model_channels']
     temb = 4 * mc
     ctx = cfg['context_dim']
@@ -164,7 +174,9 @@ def unet_param_shapes(cfg, adapter=True, prefix=''):
     p[prefix + 'time_embed.0.bias'] = (temb,)
     p[prefix + 'time_embed.2.weight'] = (temb, temb)
     p[prefix + 'time_embed.2.bias'] = (temb,)
-    if adapter:
+    if adapter == 'time':
+        p.update(time_adapter_param_shapes(cfg['in_channels'], temb=temb, prefix=prefix + 'adapter.'))
+    elif adapter:
         p.update(adapter_param_shapes(cfg['in_channels'], prefix=prefix + 'adapter.'))
     for i, layers in enumerate(inp):
         _block_params(p, f'{prefix}input_blocks.{i}.', layers, temb, ctx)

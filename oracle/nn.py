@@ -48,9 +48,13 @@ def time_embed(p, prefix, t, mc):
     return _lin(e, p, prefix + 'time_embed.2')
 
 
-def resblock(p, pre, x, emb):
-    # openaimodel.py:284-301 (no up/down, no scale-shift norm, dropout p=0)
-    h = _conv(F.silu(_gn(x, p, pre + 'in_layers.0', 1e-5)), p, pre + 'in_layers.2')
+def resblock(p, pre, x, emb, down=False):
+    # openaimodel.py:275-301 (no scale-shift norm, dropout p=0); down=True: AvgPool2d(2) on h and x (:276-282, use_conv=False)
+    h = F.silu(_gn(x, p, pre + 'in_layers.0', 1e-5))
+    if down:
+        h = F.avg_pool2d(h, 2, 2)
+        x = F.avg_pool2d(x, 2, 2)
+    h = _conv(h, p, pre + 'in_layers.2')
     e = _lin(F.silu(emb), p, pre + 'emb_layers.1')
     h = h + e[:, :, None, None]
     h = _conv(F.silu(_gn(h, p, pre + 'out_layers.0', 1e-5)), p, pre + 'out_layers.3')
@@ -142,6 +146,18 @@ def adapter_forward(p, pre, x, cin=4):
     return feats
 
 
+def time_adapter_forward(p, pre, x, emb, cin=4):
+    # adapter.py:405-417
+    feats = []
+    x = F.conv2d(x, p[pre + 'conv_in.weight'], p[pre + 'conv_in.bias'], padding=1)
+    body = arch.adapter_blocks(cin)
+    for k, (ic, oc, down) in enumerate(body):
+        x = resblock(p, f'{pre}body.{k}.', x, emb, down=down)
+        if k % 2 == 1:
+            feats.append(x)
+    return feats
+
+
 def unet_forward(p, cfg, x, t, ctx, prefix='', use_adapter=False, pcond=None,
                  control=None, only_mid_control=False):
     """eps = UNet(x, t, ctx).
@@ -155,7 +171,9 @@ def unet_forward(p, cfg, x, t, ctx, prefix='', use_adapter=False, pcond=None,
     emb = time_embed(p, prefix, t, cfg['model_channels'])
     h = x.float()
     fa = None
-    if use_adapter:
+    if use_adapter == 'time':      # use_time_adapter=True: fa = self.adapter(prompt, emb)  (openaimodel.py:843-844)
+        fa = time_adapter_forward(p, prefix + 'adapter.', h if pcond is None else pcond, emb, cfg['in_channels'])
+    elif use_adapter:
         fa = adapter_forward(p, prefix + 'adapter.', h if pcond is None else pcond, cfg['in_channels'])
     hs = []
     k = 0

@@ -61,6 +61,21 @@ def test_unet_full_width_vs_reference_goldens(sd_engine):
         assert report(f'unet FG-DM adapter {hw}x{hw} vs reference golden', relerr(e.cpu(), g[f'eps_fgdm{hw}']), NET_TOL) < NET_TOL
 
 
+def test_time_adapter_unet_vs_reference_goldens():
+    """use_time_adapter=True: TimeAdapter features from time-conditioned ResBlocks (adapter.py:387-417)."""
+    from fgdm_amd import _lib
+    e = build_engine(gi.SD_CFG, lambda k: k, use_adapter='time')
+    try:
+        g = gold('unet_full')
+        ctx = gi.get('unet/ctx')
+        t = torch.from_numpy(g['t'])
+        for hw in (8, 16):
+            eps = e.apply_model(gi.get(f'unet/x{hw}'), t, ctx, flags=_lib.FLAG_NO_CONTROL)
+            assert report(f'unet TimeAdapter {hw}x{hw} vs reference golden', relerr(eps.cpu(), g[f'eps_tadapt{hw}']), NET_TOL) < NET_TOL
+    finally:
+        e.close()
+
+
 def test_controlnet_full_width_vs_reference_goldens():
     from fgdm_amd import _lib
     # ControlledUnetModel has no adapter: separate engine without it (keys identical to the golden's)

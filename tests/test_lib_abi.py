@@ -45,6 +45,11 @@ def test_param_table_matches_reference_keys(lib):
     cn = _strip(got, 'control_model.')
     assert list(cn.keys()) == list(ref['controlnet'].keys())
     assert all(tuple(ref['controlnet'][k]) == v for k, v in cn.items())
+    # TimeAdapter variant (use_time_adapter=True)
+    got = eng.param_shapes(eng.make_config(gi.SD_CFG, use_adapter='time'))
+    unet = _strip(got, 'model.diffusion_model.')
+    assert list(unet.keys()) == list(ref['unet_time_adapter'].keys())
+    assert all(tuple(ref['unet_time_adapter'][k]) == v for k, v in unet.items())
     # plain SD UNet (= ControlledUnetModel keys)
     got = eng.param_shapes(eng.make_config(gi.SD_CFG))
     unet = _strip(got, 'model.diffusion_model.')

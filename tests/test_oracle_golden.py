@@ -23,6 +23,7 @@ def test_param_keys_match_reference():
             assert list(s) == theirs[k], k
     chk(arch.unet_param_shapes(gi.SD_CFG, adapter=True), ref['unet_fgdm'])
     chk(arch.unet_param_shapes(gi.SD_CFG, adapter=False), ref['unet_plain'])
+    chk(arch.unet_param_shapes(gi.SD_CFG, adapter='time'), ref['unet_time_adapter'])
     chk(arch.unet_param_shapes(gi.SD_CFG, adapter=False), ref['controlled_unet'])
     chk(arch.controlnet_param_shapes(gi.SD_CFG), ref['controlnet'])
     chk(arch.unet_param_shapes(gi.SMALL_CFG, adapter=False), ref['unet_small'])
@@ -152,6 +153,10 @@ def test_unet_full_width():
         assert relerr(e, g[f'eps_orig{hw}']) < TOL
         e = onn.unet_forward(p, gi.SD_CFG, x, t, ctx, prefix='model.diffusion_model.', use_adapter=True)
         assert relerr(e, g[f'eps_fgdm{hw}']) < TOL
+    pt = params(arch.unet_param_shapes(gi.SD_CFG, adapter='time'), 'model.diffusion_model.')
+    for hw in (8, 16):
+        e = onn.unet_forward(pt, gi.SD_CFG, gi.get(f'unet/x{hw}'), t, ctx, prefix='model.diffusion_model.', use_adapter='time')
+        assert relerr(e, g[f'eps_tadapt{hw}']) < TOL
 
 
 def test_controlnet_full_width():

@@ -153,6 +153,7 @@ def g_param_keys():
         sd = lambda m: {k: list(v.shape) for k, v in m.state_dict().items()}
         out['unet_fgdm'] = sd(UNetModel(**ref_cfg(gi.SD_CFG)))
         out['unet_plain'] = sd(UNetModel(**ref_cfg(gi.SD_CFG, no_prompting=True)))
+        out['unet_time_adapter'] = sd(UNetModel(**ref_cfg(gi.SD_CFG, use_time_adapter=True)))
         out['controlnet'] = sd(ControlNet(**ref_cfg(gi.SD_CFG, hint_channels=3)))
         out['controlled_unet'] = sd(ControlledUnetModel(**ref_cfg(gi.SD_CFG)))
         out['unet_small'] = sd(UNetModel(**ref_cfg(gi.SMALL_CFG, no_prompting=True)))
@@ -240,6 +241,10 @@ def g_unet_full():
             x = gi.get(f'unet/x{hw}')
             arrs[f'eps_orig{hw}'] = m(x, t, context=ctx, use_original=True)
             arrs[f'eps_fgdm{hw}'] = m(x, t, context=ctx)
+        mt = UNetModel(**ref_cfg(gi.SD_CFG, use_time_adapter=True)).eval()
+        load_synth(mt, 'model.diffusion_model.')
+        for hw in (8, 16):
+            arrs[f'eps_tadapt{hw}'] = mt(gi.get(f'unet/x{hw}'), t, context=ctx)
     save('unet_full', **arrs)
 
 
