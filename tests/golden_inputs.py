@@ -39,6 +39,8 @@ TABLE = {
     'sunet/x_T': ('sunet.xT', (2, 4, 16, 16)),
     'sunet/c': ('sunet.c', (2, 77, 768)),
     'sunet/uc': ('sunet.uc', (2, 77, 768)),
+    'vae/z8': ('vae.z8', (2, 4, 8, 8)),
+    'vae/z16': ('vae.z16', (1, 4, 16, 16)),
 }
 
 
@@ -47,6 +49,8 @@ def get(key, seed=7):
     x = torch.from_numpy(synth._rng(name, seed).standard_normal(shape, dtype=np.float32))
     if key in ('ops/gn5_x', 'ops/gn6_x'):
         x = x * 3.0 + 0.5
+    if key.startswith('vae/'):
+        x = x * 0.18215          # latents as the sampler returns them (scaled by scale_factor)
     if key == 'samp/mask':
         x = (x > 0).float()
     return x

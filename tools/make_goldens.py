@@ -159,9 +159,39 @@ def g_param_keys():
         out['unet_small'] = sd(UNetModel(**ref_cfg(gi.SMALL_CFG, no_prompting=True)))
         out['controlnet_small'] = sd(ControlNet(**ref_cfg(gi.SMALL_CFG, hint_channels=3)))
         out['unet_narrow'] = sd(UNetModel(**ref_cfg(gi.NARROW_CFG, no_prompting=True)))
+        from ldm.models.autoencoder import AutoencoderKL
+        vae = sd(AutoencoderKL(ddconfig=vae_ddconfig(), lossconfig={'target': 'torch.nn.Identity'}, embed_dim=4))
+        out['vae_decoder'] = {'first_stage_model.' + k: v for k, v in vae.items()
+                              if k.startswith(('decoder.', 'post_quant_conv.'))}
     with open(os.path.join(GOLD, 'param_keys.json'), 'w') as f:
         json.dump(out, f)
     print('wrote param_keys.json', {k: len(v) for k, v in out.items()})
+
+
+def vae_ddconfig():
+    from oracle import vae as ovae
+    c = ovae.SD_VAE
+    return dict(double_z=True, z_channels=c['z_channels'], resolution=c['resolution'], in_channels=c['in_channels'],
+                out_ch=c['out_ch'], ch=c['ch'], ch_mult=list(c['ch_mult']), num_res_blocks=c['num_res_blocks'],
+                attn_resolutions=[], dropout=0.0)
+
+
+def g_vae():
+    """First-stage decoder: the reference's AutoencoderKL.decode on z / scale_factor."""
+    from ldm.models.autoencoder import AutoencoderKL
+    from oracle import vae as ovae
+    m = AutoencoderKL(ddconfig=vae_ddconfig(), lossconfig={'target': 'torch.nn.Identity'}, embed_dim=4).eval()
+    load_synth(m, 'first_stage_model.')
+    out = {}
+    with torch.no_grad():
+        for key in ('vae/z8', 'vae/z16'):
+            z = gi.get(key)
+            out['img_' + key.split('/')[1]] = m.decode(1.0 / ovae.SCALE_FACTOR * z)
+        # the attention block alone (single head, d = 512) on the conv_in features of z8
+        z = m.post_quant_conv(1.0 / ovae.SCALE_FACTOR * gi.get('vae/z8'))
+        h = m.decoder.mid.block_1(m.decoder.conv_in(z), None)
+        out['mid_attn_z8'] = m.decoder.mid.attn_1(h)
+    save('vae', **out)
 
 
 # --------------------------------------------------------------------------- G3 per-op
@@ -480,7 +510,7 @@ def g_sampler_unet():
 
 ALL = dict(schedule=g_schedule, ddpm_schedule=g_ddpm_schedule, param_keys=g_param_keys, ops=g_ops,
            unet_full=g_unet_full, controlnet_full=g_controlnet_full, small_nets=g_small_nets,
-           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet)
+           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet, vae=g_vae)
 
 
 def main():
