@@ -26,6 +26,9 @@ class FgdmConfig(C.Structure):
         ('n_attention_resolutions', C.c_int32), ('attention_resolutions', C.c_int32 * MAX_LEVELS),
         ('num_heads', C.c_int32), ('context_dim', C.c_int32), ('use_adapter', C.c_int32),
         ('n_controlnets', C.c_int32), ('hint_channels', C.c_int32), ('workspace_bytes', C.c_int64),
+        ('vae_ch', C.c_int32), ('vae_n_levels', C.c_int32), ('vae_ch_mult', C.c_int32 * MAX_LEVELS),
+        ('vae_num_res_blocks', C.c_int32), ('vae_z_channels', C.c_int32), ('vae_out_ch', C.c_int32),
+        ('reserved_', C.c_int32),
     ]
 
 
@@ -45,6 +48,7 @@ SIGNATURES = {
     'fgdm_finalize_weights': (_i, [_p]),
     'fgdm_set_hint': (_i, [_p, _i, _p, _i, _i, _i, _p]),
     'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    'fgdm_vae_decode': (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
     'fgdm_controlnet': (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p, _i64, _p]),
     'fgdm_ddim_step': (_i, [_p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i64, _p]),
     'fgdm_plms_combine': (_i, [_p, _p, _p, _p, _i, _p, _i64, _p]),

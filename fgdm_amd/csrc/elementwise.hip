@@ -233,3 +233,59 @@ int ancestral_step(const float* x, const float* eps, float sqrt_recip, float sqr
                        coef2, std, noise, out, n);
     return LAUNCH_OK();
 }
+
+// ---------------------------------------------------------------- first-stage decoder helpers
+// post_quant_conv (1x1, 4 -> 4; ldm/models/autoencoder.py:331) applied to scale * z, fused with the layout change:
+// z [B, 4, HW] fp32  ->  y [B, HW, 4] fp16.   wb = 16 weights [co][ci] then 4 biases (device, fp32)
+__global__ void k_vae_prequant(const float* __restrict__ z, const float* __restrict__ wb, float scale,
+                               half_t* __restrict__ y, int B, int HW) {
+    const size_t n = (size_t)B * HW;
+    EW_LOOP(i, n) {
+        const size_t b = i / HW, p = i - b * HW;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = scale * z[(b * 4 + c) * HW + p];
+        h4 o;
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            float acc = wb[16 + co];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) acc += wb[co * 4 + ci] * v[ci];
+            o[co] = (half_t)acc;
+        }
+        *(h4*)(y + i * 4) = o;
+    }
+}
+int vae_prequant(const float* z, const float* wb, float scale, half_t* y, int B, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(k_vae_prequant, dim3(ew_grid((size_t)B * HW)), dim3(EW_BLOCK), 0, s, z, wb, scale, y, B, HW);
+    return LAUNCH_OK();
+}
+
+// P[r][:] = softmax(S[r][:]) over `cols` fp32 logits -> fp16 probabilities; one 256-thread block per row
+// (AttnBlock, ldm/modules/diffusionmodules/model.py:190-192: single head, the T x T score matrix of one image)
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ S, half_t* __restrict__ P, int cols) {
+    __shared__ float red[8];
+    const float* row = S + (size_t)blockIdx.x * cols;
+    half_t* out = P + (size_t)blockIdx.x * cols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int c = tid; c < cols; c += 256) m = fmaxf(m, row[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = tid; c < cols; c += 256) sum += __expf(row[c] - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int c = tid; c < cols; c += 256) out[c] = (half_t)(__expf(row[c] - m) * inv);
+}
+int softmax_rows(const float* S, half_t* P, int rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return FGDM_ERR_ARG;
+    hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, s, S, P, cols);
+    return LAUNCH_OK();
+}

@@ -129,6 +129,22 @@ struct Net {
     Tensor guided;                                         // cached input_hint_block output (persistent hipMalloc)
 };
 
+// First-stage decoder (AutoencoderKL.decode; ldm/modules/diffusionmodules/model.py:462-560)
+struct VRes { int cin = 0, cout = 0; std::string pre; NormW n1, n2; GemmW c1, c2, nin; };
+struct VLevel { std::vector<VRes> blocks; bool up = false; std::string up_pre; GemmW upconv; };
+struct Vae {
+    bool on = false, packed = false;
+    std::string prefix;
+    int top = 0, factor = 1;
+    GemmW conv_in, conv_out;
+    VRes mid1, mid2;
+    std::string attn_pre;
+    NormW attn_norm; GemmW aq, ak, av, ao;
+    std::vector<VLevel> levels;            // execution order: deepest level first
+    NormW norm_out;
+    float* pq = nullptr;                   // post_quant_conv: 16 weights [co][ci] + 4 biases
+};
+
 static int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
 // Built-in kernel timer: when enabled, every launch is bracketed by HIP events recorded on the launch stream
@@ -185,6 +201,7 @@ struct fgdm_engine {
     std::unordered_map<std::string, ParamSlot> params;
     Net unet;
     std::vector<Net> cns;
+    Vae vae;
     Arena arena;
     half_t* zero = nullptr;
     std::vector<void*> weight_allocs;
@@ -343,6 +360,57 @@ struct fgdm_engine {
         reg_wb(prefix + "out.0", {mc});
         reg_wb(prefix + "out.2", {cfg.out_channels, mc, 3, 3});
     }
+    void reg_vres(VRes& r, const std::string& pre, int cin, int cout) {
+        r.cin = cin; r.cout = cout; r.pre = pre;
+        reg_wb(pre + "norm1", {cin});
+        reg_wb(pre + "conv1", {cout, cin, 3, 3});
+        reg_wb(pre + "norm2", {cout});
+        reg_wb(pre + "conv2", {cout, cout, 3, 3});
+        if (cin != cout) reg_wb(pre + "nin_shortcut", {cout, cin, 1, 1});
+    }
+    // Decoder.__init__ (model.py:486-530) + post_quant_conv (autoencoder.py:303); keys in module-registration order
+    int build_vae() {
+        const int L = cfg.vae_n_levels, ch = cfg.vae_ch, nrb = cfg.vae_num_res_blocks;
+        if (L < 1 || L > FGDM_MAX_LEVELS || (ch & 63) || nrb < 0 || cfg.vae_z_channels != 4 || cfg.vae_out_ch < 1 || cfg.vae_out_ch > 8)
+            return fail(FGDM_ERR_ARG, "unsupported first-stage decoder config (ch multiple of 64, z_channels 4, no attention at up levels)");
+        Vae& v = vae;
+        v.on = true;
+        v.prefix = "first_stage_model.";
+        v.factor = 1 << (L - 1);
+        const std::string d = v.prefix + "decoder.";
+        v.top = ch * cfg.vae_ch_mult[L - 1];
+        reg_wb(d + "conv_in", {v.top, 4, 3, 3});
+        reg_vres(v.mid1, d + "mid.block_1.", v.top, v.top);
+        v.attn_pre = d + "mid.attn_1.";
+        reg_wb(v.attn_pre + "norm", {v.top});
+        for (const char* n : {"q", "k", "v", "proj_out"}) reg_wb(v.attn_pre + n, {v.top, v.top, 1, 1});
+        reg_vres(v.mid2, d + "mid.block_2.", v.top, v.top);
+        std::vector<VLevel> asc(L);
+        int block_in = v.top;
+        for (int lvl = L - 1; lvl >= 0; --lvl) {      // channel bookkeeping in execution order (model.py:501-511)
+            const int block_out = ch * cfg.vae_ch_mult[lvl];
+            for (int i = 0; i <= nrb; ++i) { VRes r; r.cin = block_in; r.cout = block_out; asc[lvl].blocks.push_back(r); block_in = block_out; }
+            asc[lvl].up = lvl != 0;
+        }
+        for (int lvl = 0; lvl < L; ++lvl) {           // registration order: `self.up.insert(0, up)` -> ascending
+            const std::string lp = d + "up." + std::to_string(lvl) + ".";
+            for (size_t i = 0; i < asc[lvl].blocks.size(); ++i) {
+                VRes& r = asc[lvl].blocks[i];
+                reg_vres(r, lp + "block." + std::to_string(i) + ".", r.cin, r.cout);
+            }
+            if (asc[lvl].up) {
+                const int c = asc[lvl].blocks.back().cout;
+                asc[lvl].up_pre = lp + "upsample.conv";
+                reg_wb(asc[lvl].up_pre, {c, c, 3, 3});
+            }
+        }
+        for (int lvl = L - 1; lvl >= 0; --lvl) v.levels.push_back(asc[lvl]);
+        const int c0 = ch * cfg.vae_ch_mult[0];
+        reg_wb(d + "norm_out", {c0});
+        reg_wb(d + "conv_out", {cfg.vae_out_ch, c0, 3, 3});
+        reg_wb(v.prefix + "post_quant_conv", {4, 4, 1, 1});
+        return FGDM_OK;
+    }
     int build() {
         if (cfg.n_levels < 1 || cfg.n_levels > FGDM_MAX_LEVELS || cfg.model_channels <= 0 || (cfg.model_channels & 63) ||
             cfg.num_heads <= 0 || cfg.n_controlnets < 0 || cfg.n_controlnets > FGDM_MAX_CONTROLNETS ||
@@ -359,6 +427,7 @@ struct fgdm_engine {
         cns.resize(cfg.n_controlnets);
         for (int k = 0; k < cfg.n_controlnets; ++k)
             build_net(cns[k], k == 0 ? std::string("control_model.") : "control_model_" + std::to_string(k) + ".", true, 0);
+        if (cfg.vae_ch > 0) return build_vae();
         return FGDM_OK;
     }
 
@@ -539,6 +608,44 @@ struct fgdm_engine {
         // staging for this net is no longer needed
         for (auto& name : order)
             if (name.compare(0, n.prefix.size(), n.prefix) == 0) { auto& ps = params[name]; std::vector<float>().swap(ps.host); }
+        return FGDM_OK;
+    }
+
+    int pack_vres(VRes& r) {
+        CHK(pack_norm(r.n1, r.pre + "norm1"));
+        CHK(pack_conv3(r.c1, r.pre + "conv1"));
+        CHK(pack_norm(r.n2, r.pre + "norm2"));
+        CHK(pack_conv3(r.c2, r.pre + "conv2"));
+        if (r.cin != r.cout) CHK(pack_linear(r.nin, r.pre + "nin_shortcut", true));
+        return FGDM_OK;
+    }
+    int pack_vae() {
+        Vae& v = vae;
+        const std::string d = v.prefix + "decoder.";
+        CHK(pack_conv3(v.conv_in, d + "conv_in"));
+        CHK(pack_vres(v.mid1));
+        CHK(pack_norm(v.attn_norm, v.attn_pre + "norm"));
+        CHK(pack_linear(v.aq, v.attn_pre + "q", true));
+        CHK(pack_linear(v.ak, v.attn_pre + "k", true));
+        CHK(pack_linear(v.av, v.attn_pre + "v", true));
+        CHK(pack_linear(v.ao, v.attn_pre + "proj_out", true));
+        CHK(pack_vres(v.mid2));
+        for (auto& lv : v.levels) {
+            for (auto& r : lv.blocks) CHK(pack_vres(r));
+            if (lv.up) CHK(pack_conv3(lv.upconv, lv.up_pre));
+        }
+        CHK(pack_norm(v.norm_out, d + "norm_out"));
+        CHK(pack_conv3(v.conv_out, d + "conv_out"));
+        const ParamSlot* w = slot(v.prefix + "post_quant_conv.weight");
+        const ParamSlot* b = slot(v.prefix + "post_quant_conv.bias");
+        if (!w || !b) return FGDM_ERR_STATE;
+        std::vector<float> wb(w->host);
+        wb.insert(wb.end(), b->host.begin(), b->host.end());
+        v.pq = upload(wb);
+        if (!v.pq) return fail(FGDM_ERR_NOMEM, "hipMalloc failed");
+        for (auto& name : order)
+            if (name.compare(0, v.prefix.size(), v.prefix) == 0) { auto& ps = params[name]; std::vector<float>().swap(ps.host); }
+        v.packed = true;
         return FGDM_OK;
     }
 
@@ -972,6 +1079,95 @@ struct fgdm_engine {
         return FGDM_OK;
     }
 
+    // ------------------------------------------------------------------------------------ first-stage decoder
+    // ResnetBlock.forward with temb = None (model.py:121-141); Normalize = GroupNorm(32, eps 1e-6), swish = SiLU
+    int vres_fwd(const VRes& r, const Tensor& x, Tensor* out) {
+        Tensor g1, h, g2, sk;
+        CHK(gnorm(r.n1, x, nullptr, 1e-6f, true, &g1));
+        CHK(conv3(r.c1, g1, nullptr, 1, false, Epi{}, &h));
+        tfree(g1);
+        CHK(gnorm(r.n2, h, nullptr, 1e-6f, true, &g2));
+        tfree(h);
+        Epi e2;
+        if (r.cin != r.cout) { CHK(linear(r.nin, x, Epi{}, &sk)); e2.resid = sk.p; e2.ld_res = sk.C; }
+        else { e2.resid = x.p; e2.ld_res = x.C; }
+        CHK(conv3(r.c2, g2, nullptr, 1, false, e2, out));
+        tfree(g2);
+        if (sk.p) tfree(sk);
+        return FGDM_OK;
+    }
+    // AttnBlock.forward (model.py:176-203): ONE head over all C channels.  d = C = 512 does not fit the flash kernel's
+    // register budget, so per image: S = C^-1/2 Q K^T (fp32, GEMM with K as the "weight"), row softmax, O = P V
+    // (GEMM with V^T, written transposed by the v projection's epilogue, as the weight).
+    int vattn_fwd(const Tensor& x, Tensor* out) {
+        const Vae& v = vae;
+        const int B = x.B, T = x.H * x.W, C = x.C;
+        if (T & 63) return fail(FGDM_ERR_ARG, "first-stage attention: H*W must be a multiple of 64");
+        Tensor g, q, k, vt, a, P;
+        CHK(gnorm(v.attn_norm, x, nullptr, 1e-6f, false, &g));
+        CHK(linear(v.aq, g, Epi{}, &q));
+        k = talloc(1, 1, B * T + 128, C);        // + 128 rows: the GEMM reads whole 128-row weight tiles
+        vt = talloc(B, 1, C, T);
+        a = talloc(B, x.H, x.W, C);
+        P = talloc(1, 1, T, T);
+        float* S = (float*)arena.alloc((size_t)T * T * sizeof(float));
+        if (!k.p || !vt.p || !a.p || !P.p || !S) return fail(FGDM_ERR_NOMEM, "workspace");
+        HIP_TRY(hipMemsetAsync(k.p + (size_t)B * T * C, 0, (size_t)128 * C * sizeof(half_t), s));
+        { Epi e; e.out = k.p; e.ld_out = C; e.rps = T; CHK(linear(v.ak, g, e, nullptr)); }
+        { Epi e; e.out_kind = OUT_F16_T; e.out = vt.p; e.ld_out = T; e.rps = T; CHK(linear(v.av, g, e, nullptr)); }
+        tfree(g);
+        for (int b = 0; b < B; ++b) {
+            GemmW wk; wk.w = k.p + (size_t)b * T * C; wk.N = T; wk.K = C; wk.k_real = C;
+            Tensor qb; qb.p = q.p + (size_t)b * T * C; qb.B = 1; qb.H = 1; qb.W = T; qb.C = C;
+            { Epi e; e.out_kind = OUT_F32; e.out = S; e.ld_out = T; e.rps = T; e.scale = 1.0f / sqrtf((float)C);
+              CHK(gemm(wk, IG_LINEAR, qb, nullptr, 1, T, e, nullptr)); }
+            if (softmax_rows(S, P.p, T, T, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "softmax kernel");
+            GemmW wv; wv.w = vt.p + (size_t)b * C * T; wv.N = C; wv.K = T; wv.k_real = T;
+            { Epi e; e.out = a.p + (size_t)b * T * C; e.ld_out = C; e.rps = T;
+              CHK(gemm(wv, IG_LINEAR, P, nullptr, 1, T, e, nullptr)); }
+        }
+        arena.release(S);
+        tfree(P); tfree(q); tfree(k); tfree(vt);
+        { Epi e; e.resid = x.p; e.ld_res = C; CHK(linear(v.ao, a, e, out)); }
+        tfree(a);
+        return FGDM_OK;
+    }
+    // LatentDiffusion.decode_first_stage (ddpm.py:839,889) -> AutoencoderKL.decode (autoencoder.py:330-333) ->
+    // Decoder.forward (model.py:532-560).  z fp32 NCHW [B,4,H,W] -> image fp32 NCHW [B,out_ch,f*H,f*W]
+    int vae_decode(const float* z, int B, int H, int W, float scale, float* out) {
+        if (!vae.on) return fail(FGDM_ERR_STATE, "engine was created without a first-stage decoder (vae_ch = 0)");
+        if (!vae.packed) return fail(FGDM_ERR_STATE, "weights not finalized");
+        if (B <= 0 || H <= 0 || W <= 0) return fail(FGDM_ERR_ARG, "bad shape");
+        const Vae& v = vae;
+        const int f = v.factor, HW = H * W;
+        const size_t out_per_img = (size_t)cfg.vae_out_ch * H * f * W * f;
+        // images per pass: ~8 live full-resolution tensors of `ch` channels must fit comfortably in one slab
+        const size_t big = (size_t)H * f * W * f * cfg.vae_ch * sizeof(half_t) * 8;
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)3 << 30) / std::max<size_t>(big, 1)));
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = std::min(chunk, B - b0);
+            Tensor z4 = talloc(nb, H, W, 4), h, t;
+            if (!z4.p) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (vae_prequant(z + (size_t)b0 * 4 * HW, v.pq, scale, z4.p, nb, HW, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "prequant kernel");
+            CHK(conv3(v.conv_in, z4, nullptr, 1, false, Epi{}, &h));
+            tfree(z4);
+            CHK(vres_fwd(v.mid1, h, &t)); tfree(h); h = t;
+            CHK(vattn_fwd(h, &t)); tfree(h); h = t;
+            CHK(vres_fwd(v.mid2, h, &t)); tfree(h); h = t;
+            for (const VLevel& lv : v.levels) {
+                for (const VRes& r : lv.blocks) { CHK(vres_fwd(r, h, &t)); tfree(h); h = t; }
+                if (lv.up) { CHK(conv3(lv.upconv, h, nullptr, 1, true, Epi{}, &t)); tfree(h); h = t; }
+            }
+            Tensor g;
+            CHK(gnorm(v.norm_out, h, nullptr, 1e-6f, true, &g));
+            tfree(h);
+            { Epi e; e.out_kind = OUT_F32_NCHW; e.out = out + (size_t)b0 * out_per_img; e.ld_out = g.H * g.W;
+              CHK(conv3(v.conv_out, g, nullptr, 1, false, e, nullptr)); }
+            tfree(g);
+        }
+        return FGDM_OK;
+    }
+
     // input_hint_block (cldm.py:655-671): 8 conv3x3, SiLU between, stride 2 at convs 2/4/6; result cached
     int set_hint(int cn, const float* hint, int B, int Hh, int Wh) {
         if (!finalized) return fail(FGDM_ERR_STATE, "weights not finalized");
@@ -1120,6 +1316,7 @@ int fgdm_finalize_weights(fgdm_engine* e) {
     rc = e->pack_net(e->unet);
     if (rc != FGDM_OK) return rc;
     for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }
+    if (e->vae.on) { rc = e->pack_vae(); if (rc != FGDM_OK) return rc; }
     e->finalized = true;
     return FGDM_OK;
 }
@@ -1187,6 +1384,12 @@ int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const flo
     if (!e || !x || (!t && !t_float) || !ctx || !eps_out) return FGDM_ERR_ARG;
     e->s = as_stream(stream);
     return e->apply_model(x, t, t_float, ctx, pcond, control_scales, B, H, W, flags, eps_out);
+}
+
+int fgdm_vae_decode(fgdm_engine* e, const float* z, int B, int H, int W, float scale, float* image, void* stream) {
+    if (!e || !z || !image) return FGDM_ERR_ARG;
+    e->s = as_stream(stream);
+    return e->vae_decode(z, B, H, W, scale, image);
 }
 
 int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, const float* ctx, int B, int H, int W,

@@ -12,8 +12,13 @@ SD_V1 = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolu
              num_res_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
 
 
-def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, workspace_bytes=0):
-    """fgdm_config from the reference's UNetModel kwargs (models/config.yaml:33-48)."""
+# AutoencoderKL ddconfig of the shipped configs (models/config.yaml:55-69)
+SD_VAE = dict(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=(), z_channels=4)
+
+
+def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, workspace_bytes=0, vae=None):
+    """fgdm_config from the reference's UNetModel kwargs (models/config.yaml:33-48); `vae`: None (no first-stage
+    decoder), True (SD_VAE) or the AutoencoderKL `ddconfig` dict."""
     cfg = dict(SD_V1 if cfg is None else cfg)
     c = _lib.FgdmConfig()
     c.in_channels = cfg['in_channels']
@@ -34,6 +39,17 @@ def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, w
     c.n_controlnets = int(n_controlnets)
     c.hint_channels = hint_channels
     c.workspace_bytes = int(workspace_bytes)
+    if vae:
+        dd = dict(SD_VAE if vae is True else vae)
+        if list(dd.get('attn_resolutions', ())):
+            raise ValueError('first-stage decoder: attention at up levels (attn_resolutions) is not supported')
+        c.vae_ch = dd['ch']
+        c.vae_n_levels = len(dd['ch_mult'])
+        for i, v in enumerate(dd['ch_mult']):
+            c.vae_ch_mult[i] = v
+        c.vae_num_res_blocks = dd['num_res_blocks']
+        c.vae_z_channels = dd['z_channels']
+        c.vae_out_ch = dd['out_ch']
     return c
 
 
@@ -66,11 +82,12 @@ def _ptr(t):
 class Engine:
     """One engine per device: owns packed weights + activation workspace in HBM."""
 
-    def __init__(self, cfg=None, use_adapter=False, n_controlnets=0, device=0, workspace_bytes=0):
+    def __init__(self, cfg=None, use_adapter=False, n_controlnets=0, device=0, workspace_bytes=0, vae=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('fgdm_amd.Engine needs a GPU (MI355X); there is no CPU fallback')
-        self.config = make_config(cfg, use_adapter, n_controlnets, workspace_bytes=workspace_bytes)
+        self.config = make_config(cfg, use_adapter, n_controlnets, workspace_bytes=workspace_bytes, vae=vae)
+        self.has_vae = bool(vae)
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
         h = C.c_void_p()
@@ -177,6 +194,17 @@ class Engine:
                                        flags, _ptr(eps), _stream())
         self._check(rc, 'fgdm_apply_model')
         return eps
+
+    def vae_decode(self, z, scale=1.0):
+        """AutoencoderKL.decode(scale * z): fp32 NCHW latents [B,4,H,W] -> fp32 NCHW images [B,3,8H,8W]."""
+        z = z.to(self.device, torch.float32).contiguous()
+        B, Cc, H, W = z.shape
+        assert Cc == 4
+        f = 1 << (self.config.vae_n_levels - 1)
+        img = torch.empty(B, self.config.vae_out_ch, H * f, W * f, device=self.device, dtype=torch.float32)
+        rc = self.lib.fgdm_vae_decode(self.h, _ptr(z), B, H, W, float(scale), _ptr(img), _stream())
+        self._check(rc, 'fgdm_vae_decode')
+        return img
 
     def controlnet(self, cn, x, t, ctx):
         """The 13 ControlNet residuals (fp32 NCHW), for inspection / tests."""

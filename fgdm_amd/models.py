@@ -8,8 +8,9 @@
 They expose what the samplers and the inference scripts require of `model`: num_timesteps, betas,
 alphas_cumprod(_prev), device, parameterization, apply_model, q_sample, control_scales, cuda()/to()/eval(),
 ema_scope(), load_state_dict().  All network arithmetic runs in the HIP engine; the per-step latent updates run
-in the sampler kernels.  CLIP text encoding and VAE decoding are outside this path (SURVEY section 8f "next" rows): plug
-callables in via `cond_stage_model` / `first_stage_decode`.
+in the sampler kernels.  decode_first_stage (ddpm.py:832-889) runs in the engine too when the
+model is built with a `first_stage_config`.  CLIP text encoding is outside this path: plug a callable in via
+`cond_stage_model`.
 """
 import contextlib
 
@@ -47,13 +48,15 @@ class LatentDiffusion(_Buffers):
     def __init__(self, unet_config=None, engine=None, use_adapter=True, n_controlnets=0, timesteps=1000,
                  beta_schedule='linear', linear_start=0.00085, linear_end=0.012, cosine_s=8e-3, given_betas=None,
                  v_posterior=0.0, parameterization='eps', conditioning_key='crossattn', scale_factor=0.18215,
-                 channels=4, image_size=32, log_every_t=200, clip_denoised=False, device=0, **ignored):
+                 channels=4, image_size=32, log_every_t=200, clip_denoised=False, device=0, first_stage_config=None,
+                 **ignored):
         if parameterization != 'eps':
             raise NotImplementedError('only eps-parameterization is used by the shipped configs (models/config.yaml)')
         if conditioning_key != 'crossattn':
             raise NotImplementedError("only conditioning_key='crossattn' is on the hot path (models/config.yaml:15)")
         self.engine = engine if engine is not None else _k.Engine(unet_config, use_adapter=use_adapter,
-                                                                   n_controlnets=n_controlnets, device=device)
+                                                                   n_controlnets=n_controlnets, device=device,
+                                                                   vae=self._ddconfig(first_stage_config))
         self.device = self.engine.device
         self.model = DiffusionWrapper(self.engine, conditioning_key)
         self.parameterization = parameterization
@@ -65,11 +68,24 @@ class LatentDiffusion(_Buffers):
         self.clip_denoised = clip_denoised
         self.shorten_cond_schedule = False
         self.cond_stage_model = None        # callable(list[str]) -> [B,77,768]   (CLIP; out of scope here)
-        self.first_stage_decode = None      # callable(z) -> image                (VAE; out of scope here)
+        self.first_stage_decode = None      # optional callable(z / scale_factor) -> image overriding the engine's decoder
         self._register_schedule(self.device, kind=beta_schedule, timesteps=timesteps, linear_start=linear_start,
                                 linear_end=linear_end, cosine_s=cosine_s, v_posterior=v_posterior,
                                 given_betas=given_betas)
         self._finalized = False
+
+    @staticmethod
+    def _ddconfig(first_stage_config):
+        """first_stage_config as in models/config.yaml:50-71 ({'target': ..., 'params': {'ddconfig': {...}}}), a bare
+        ddconfig dict, True (SD-v1 decoder) or None (no decoder in the engine)."""
+        if not first_stage_config:
+            return None
+        if first_stage_config is True:
+            return True
+        fc = dict(first_stage_config)
+        if 'params' in fc:
+            fc = dict(fc['params'])
+        return dict(fc.get('ddconfig', fc))
 
     # ---- nn.Module-ish surface the scripts touch (scripts/txt2img_fgdm_inference.py:23-38,179-180,216-218)
     def cuda(self, *a, **k):
@@ -87,7 +103,8 @@ class LatentDiffusion(_Buffers):
 
     def load_state_dict(self, sd, strict=False):
         missing = self.engine.load_state_dict(sd, strict=strict)
-        unexpected = [k for k in sd if not (k.startswith('model.diffusion_model.') or k.startswith('control_model'))]
+        want = self.engine.param_shapes()
+        unexpected = [k for k in sd if k not in want]
         if not missing:
             self.engine.finalize()
             self._finalized = True
@@ -99,11 +116,16 @@ class LatentDiffusion(_Buffers):
                                       'set model.cond_stage_model to a callable returning [B,77,768]')
         return self.cond_stage_model(c)
 
-    def decode_first_stage(self, z, **kw):
-        if self.first_stage_decode is None:
-            raise NotImplementedError('VAE decode is outside the accelerated path (next row); '
-                                      'set model.first_stage_decode to a callable')
-        return self.first_stage_decode(z)
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False, n=None):
+        """ddpm.py:832-889 for an AutoencoderKL first stage: decode(z / scale_factor)."""
+        if predict_cids:
+            raise NotImplementedError('predict_cids needs a VQ first stage; every shipped config uses AutoencoderKL')
+        if self.first_stage_decode is not None:
+            return self.first_stage_decode(1. / self.scale_factor * z)
+        if not self.engine.has_vae:
+            raise NotImplementedError('this model was built without first_stage_config; pass one (or set '
+                                      'model.first_stage_decode to a callable)')
+        return self.engine.vae_decode(z, 1. / self.scale_factor)
 
     # ---- apply_model (ddpm.py:1035-1044,1130-1136 non-tiled branch; DiffusionWrapper crossattn mode)
     @staticmethod

@@ -37,6 +37,11 @@ typedef struct fgdm_config {
     int32_t n_controlnets;     /* 0..FGDM_MAX_CONTROLNETS ControlNet twin encoders (cldm.py:545-790) */
     int32_t hint_channels;     /* 3 */
     int64_t workspace_bytes;   /* initial activation slab; 0 = default; grows on demand */
+    /* First-stage decoder (AutoencoderKL ddconfig, models/config.yaml:55-69); vae_ch = 0: engine without a decoder */
+    int32_t vae_ch, vae_n_levels;
+    int32_t vae_ch_mult[FGDM_MAX_LEVELS];
+    int32_t vae_num_res_blocks, vae_z_channels, vae_out_ch;
+    int32_t reserved_;
 } fgdm_config;
 
 #define FGDM_DTYPE_F32 0
@@ -77,6 +82,13 @@ int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int 
 int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* t_float, const float* ctx,
                      const float* pcond, const float* control_scales, int B, int H, int W, int flags, float* eps_out,
                      void* stream);
+
+/* First-stage decode: LatentDiffusion.decode_first_stage (ldm/models/diffusion/ddpm.py:832-889, plain branch) =
+ * AutoencoderKL.decode(scale * z) (ldm/models/autoencoder.py:330-333; Decoder.forward,
+ * ldm/modules/diffusionmodules/model.py:532-560).  z fp32 NCHW [B,4,H,W] (device), scale = 1 / scale_factor;
+ * image fp32 NCHW [B, vae_out_ch, f*H, f*W], f = 2^(vae_n_levels-1).  Needs an engine created with vae_ch > 0 and the
+ * first_stage_model.decoder.* / first_stage_model.post_quant_conv.* tensors loaded. */
+int fgdm_vae_decode(fgdm_engine* e, const float* z, int B, int H, int W, float scale, float* image, void* stream);
 
 /* ControlNet.forward alone (cldm.py:792-813): the 13 residual tensors as fp32 NCHW, written back-to-back into
  * `out` in the order the reference returns them.  Test/inspection entry; apply_model never materialises them. */

@@ -58,6 +58,12 @@ def test_param_table_matches_reference_keys(lib):
     got = eng.param_shapes(eng.make_config(gi.SMALL_CFG, n_controlnets=1))
     assert list(_strip(got, 'model.diffusion_model.').keys()) == list(ref['unet_small'].keys())
     assert list(_strip(got, 'control_model.').keys()) == list(ref['controlnet_small'].keys())
+    # first-stage decoder keys follow the UNet / ControlNet tables (AutoencoderKL decoder.* + post_quant_conv.*)
+    got = eng.param_shapes(eng.make_config(gi.SD_CFG, vae=True))
+    vae = {k: v for k, v in got.items() if k.startswith('first_stage_model.')}
+    assert list(vae.keys()) == list(ref['vae_decoder'].keys())
+    assert all(tuple(ref['vae_decoder'][k]) == v for k, v in vae.items())
+    assert list(got.keys())[-len(vae):] == list(vae.keys())
     # several ControlNets get distinct prefixes
     got = eng.param_shapes(eng.make_config(gi.SD_CFG, n_controlnets=3))
     assert any(k.startswith('control_model_1.') for k in got) and any(k.startswith('control_model_2.') for k in got)
@@ -67,6 +73,10 @@ def test_unsupported_configs_are_rejected(lib):
     bad = dict(gi.SD_CFG, model_channels=160)          # not a multiple of 64
     with pytest.raises(ValueError):
         eng.param_shapes(eng.make_config(bad))
+    with pytest.raises(ValueError):                     # decoder attention at up levels is not implemented
+        eng.make_config(gi.SD_CFG, vae=dict(eng.SD_VAE, attn_resolutions=[32]))
+    with pytest.raises(ValueError):                     # decoder width must be a multiple of 64
+        eng.param_shapes(eng.make_config(gi.SD_CFG, vae=dict(eng.SD_VAE, ch=96)))
     with pytest.raises(ValueError):                     # adapter needs the SD-v1 topology
         eng.param_shapes(eng.make_config(gi.SMALL_CFG, use_adapter=True))
 
