@@ -40,7 +40,7 @@ def build_model(rank, world):
     shipped with ONE RCCL broadcast of a flat fp32 buffer (fgdm_amd/dist.py)."""
     from fgdm_amd import dist as fd, models, synth
     t0 = time.time()
-    model = models.ControlLDM(None, n_controlnets=1, device=torch.cuda.current_device())
+    model = models.ControlLDM(None, n_controlnets=1, device=torch.cuda.current_device(), first_stage_config=True)
     shapes = model.engine.param_shapes()
     sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, 'cuda')
     missing, _ = model.load_state_dict(sd, strict=True)
@@ -159,6 +159,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all(), 'non-finite latents'
+    # outside the timed region (VAE decode excluded from the metric, reported separately):
+    # decode_first_stage of this rank's latents to 512x512 images
+    img = model.decode_first_stage(out)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    img = model.decode_first_stage(out)
+    torch.cuda.synchronize()
+    dec_s = time.perf_counter() - t1
+    assert tuple(img.shape) == (npg, 3, 8 * LATENT, 8 * LATENT) and torch.isfinite(img).all()
 
     if rank == 0:
         # HBM traffic per launch of the dominant kernel family: measured offline with rocprofv3 PMC passes
@@ -198,6 +207,10 @@ def main():
             'attention_tflops': (prof['attention']['work'] / (prof['attention']['ms'] * 1e-3) / 1e12
                                  if prof['attention']['ms'] > 0 else 0.0),
             'norm_GBps': (prof['norm']['work'] / (prof['norm']['ms'] * 1e-3) / 1e9 if prof['norm']['ms'] > 0 else 0.0),
+            'first_stage_decode': {'ms_per_image': dec_s / npg * 1e3,
+                                   'images_per_s_including_decode': N / (dt / a.steps + dec_s),
+                                   'note': 'AutoencoderKL.decode of the sampled latents in the same engine, outside the '
+                                           'timed region; 1.27 TFLOP/image'},
             'weights': {'params': n_params, 'load_s': round(load_s, 2)},
             'workspace': engine.workspace_stats(),
         }

@@ -75,18 +75,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     float* stats = sc + 2 * C;
     // every block reduces the per-chunk partial sums of its sample itself (fixed order, double accumulation:
     // the E[x^2] - mean^2 form must not lose digits when |mean| >> std) -- no separate finalize launch
-    if (threadIdx.x < 32) {
-        const int g = threadIdx.x;
+    {   // 8 threads per group, each sums every 8th chunk; the 8 sub-sums meet in a fixed xor-shuffle tree
+        const int g = threadIdx.x >> 3, part = threadIdx.x & 7;
         double s = 0.0, q = 0.0;
-        for (int c = 0; c < nchunk; ++c) {
+        for (int c = part; c < nchunk; c += 8) {
             s += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2];
             q += (double)partial[((size_t)b * nchunk + c) * 64 + g * 2 + 1];
         }
-        const double mean = s * inv_count;
-        double var = q * inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[g * 2] = (float)mean;
-        stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+        if (part == 0) {
+            const double mean = s * inv_count;
+            double var = q * inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            stats[g * 2] = (float)mean;
+            stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
