@@ -49,6 +49,9 @@ SIGNATURES = {
     'fgdm_set_hint': (_i, [_p, _i, _p, _i, _i, _i, _p]),
     'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     'fgdm_vae_decode': (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
+    'fgdm_image_to_uint8': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    'fgdm_resize_linear_uint8': (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    'fgdm_uint8_to_hint': (_i, [_p, _i, _i, _i, _i, _p, _p]),
     'fgdm_controlnet': (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p, _i64, _p]),
     'fgdm_ddim_step': (_i, [_p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i64, _p]),
     'fgdm_plms_combine': (_i, [_p, _p, _p, _p, _i, _p, _i64, _p]),

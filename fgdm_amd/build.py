@@ -6,9 +6,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfgdm_hip.so')
-SOURCES = ['igemm.hip', 'igemm2.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'engine.hip']
+SOURCES = ['igemm.hip', 'igemm2.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'boundary.hip', 'engine.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable', '-ffp-contract=fast', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-fno-honor-nans']
+
+
+# bit-exact byte kernels: no FMA contraction (the flag comes last, so it overrides -ffp-contract=fast)
+EXTRA_FLAGS = {'boundary.hip': ['-ffp-contract=off']}
 
 
 def _hipcc():
@@ -33,7 +37,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [_hipcc(), *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -78,6 +78,9 @@ int add_f16(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s
 int timestep_embed(const int64_t* t, const float* t_float, half_t* y, int B, int dim, int rows_pad, hipStream_t s);
 int vae_prequant(const float* z, const float* wb, float scale, half_t* y, int B, int HW, hipStream_t s);
 int softmax_rows(const float* S, half_t* P, int rows, int cols, hipStream_t s);
+int image_to_u8(const float* x, uint8_t* y, int B, int C, int HW, int mode, hipStream_t s);
+int resize_linear_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+int u8_to_hint(const uint8_t* src, float* dst, int B, int HW, int C, hipStream_t s);
 int transpose_pad_keys(const half_t* v, half_t* vt, int B, int Tk, int C, int Tkpad, hipStream_t s);
 // x_prev, pred_x0 from eps (with CFG combine when e_uncond != null); all fp32 NCHW
 int ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,

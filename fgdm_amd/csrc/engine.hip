@@ -1433,6 +1433,19 @@ int fgdm_ancestral_step(const float* x, const float* eps, float sqrt_recip_ac, f
     return ancestral_step(x, eps, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, std, noise, out, (size_t)n, as_stream(stream));
 }
 
+int fgdm_image_to_uint8(const float* image, int B, int C, int H, int W, int mode, uint8_t* out, void* stream) {
+    if (!image || !out) return FGDM_ERR_ARG;
+    return image_to_u8(image, out, B, C, H * W, mode, as_stream(stream));
+}
+int fgdm_resize_linear_uint8(const uint8_t* src, int B, int H, int W, int C, int Ho, int Wo, uint8_t* dst, void* stream) {
+    if (!src || !dst) return FGDM_ERR_ARG;
+    return resize_linear_u8(src, dst, B, H, W, C, Ho, Wo, as_stream(stream));
+}
+int fgdm_uint8_to_hint(const uint8_t* src, int B, int H, int W, int C, float* hint, void* stream) {
+    if (!src || !hint) return FGDM_ERR_ARG;
+    return u8_to_hint(src, hint, B, H * W, C, as_stream(stream));
+}
+
 int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* uncond, float cfg_scale, int S,
                      const int64_t* timesteps, const float* alphas, const float* alphas_prev,
                      const float* sqrt_one_minus_alphas, const float* control_scales, int B, int H, int W, int flags,

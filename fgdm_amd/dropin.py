@@ -6,6 +6,7 @@
     from ldm.models.diffusion.ddpm import LatentDiffusion
     from controlnet.cldm.ddim_hacked import DDIMSampler        # controlnet/initialize_cn.py:16
     from controlnet.cldm.cldm import ControlLDM
+    import controlnet.initialize_cn as initialize_cn           # scripts/txt2img_fgdm_inference.py:25 (process, initialize_controlnet)
 
 install() registers lightweight module objects under those dotted names (only the sampling-path modules;
 everything else of the reference's `ldm` / `controlnet` packages is untouched if it is importable).
@@ -14,7 +15,7 @@ If the real reference packages are already imported, install(replace=True) swaps
 import sys
 import types
 
-from . import models, samplers
+from . import initialize_cn, models, samplers
 
 _MAP = {
     'ldm.models.diffusion.ddim': {'DDIMSampler': samplers.DDIMSampler},
@@ -23,6 +24,9 @@ _MAP = {
     'ldm.models.diffusion.ddpm': {'LatentDiffusion': models.LatentDiffusion, 'DiffusionWrapper': models.DiffusionWrapper},
     'controlnet.cldm.ddim_hacked': {'DDIMSampler': samplers.ControlDDIMSampler},
     'controlnet.cldm.cldm': {'ControlLDM': models.ControlLDM},
+    'controlnet.cldm.model': {'load_state_dict': initialize_cn.load_state_dict, 'get_state_dict': initialize_cn.get_state_dict},
+    'controlnet.initialize_cn': {'initialize_controlnet': initialize_cn.initialize_controlnet,
+                                 'process': initialize_cn.process},
 }
 
 

@@ -90,6 +90,17 @@ int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const flo
  * first_stage_model.decoder.* / first_stage_model.post_quant_conv.* tensors loaded. */
 int fgdm_vae_decode(fgdm_engine* e, const float* z, int B, int H, int W, float scale, float* image, void* stream);
 
+/* Stage boundary of the two-factor chain (device pointers; byte work, bit-exact to the reference's expressions):
+ *  fgdm_image_to_uint8: fp32 NCHW image -> uint8 NHWC.  mode 0 = uint8(255 * clamp((x+1)/2, 0, 1))
+ *      (scripts/txt2img_fgdm_inference.py:245,249-252); mode 1 = uint8(clip(x*127.5+127.5, 0, 255))
+ *      (controlnet/initialize_cn.py:101).
+ *  fgdm_resize_linear_uint8: cv2.resize(img, (Wo, Ho), interpolation=cv2.INTER_LINEAR) on uint8 NHWC
+ *      (scripts/txt2img_fgdm_inference.py:258; OpenCV generic fixed-point path, see oracle/boundary.py).
+ *  fgdm_uint8_to_hint: control = float(img) / 255, NHWC -> fp32 NCHW (controlnet/initialize_cn.py:78-80). */
+int fgdm_image_to_uint8(const float* image, int B, int C, int H, int W, int mode, uint8_t* out, void* stream);
+int fgdm_resize_linear_uint8(const uint8_t* src, int B, int H, int W, int C, int Ho, int Wo, uint8_t* dst, void* stream);
+int fgdm_uint8_to_hint(const uint8_t* src, int B, int H, int W, int C, float* hint, void* stream);
+
 /* ControlNet.forward alone (cldm.py:792-813): the 13 residual tensors as fp32 NCHW, written back-to-back into
  * `out` in the order the reference returns them.  Test/inspection entry; apply_model never materialises them. */
 int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, const float* ctx, int B, int H, int W,
