@@ -56,6 +56,16 @@ def get(key, seed=7):
     return x
 
 
+def clip_ids(n=2, T=77, seed=7):
+    """Token ids shaped like the CLIP tokenizer's output: BOS, words, EOS, EOS padding (max_length 77)."""
+    rng = synth._rng('clip.ids', seed)
+    ids = np.full((n, T), 49407, dtype=np.int64)
+    ids[:, 0] = 49406
+    for b, L in enumerate([9, 40, 75, 0, 23][:n]):
+        ids[b, 1:1 + L] = rng.integers(0, 49406, size=L)
+    return torch.from_numpy(ids)
+
+
 def hint(n, res, seed):
     return torch.from_numpy(synth.hint(n, res=res, seed=seed))
 

@@ -194,6 +194,41 @@ def g_vae():
     save('vae', **out)
 
 
+def g_clip():
+    """CLIP text encoder.  Third-party: FrozenCLIPEmbedder = transformers.CLIPTextModel
+    (ldm/modules/encoders/modules.py:137-162); run here from the installed transformers with synthetic weights."""
+    # transformers probes optional packages with importlib.util.find_spec: hide the spec-less stubs while importing it
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split('.')[0] in ('torchvision', 'omegaconf', 'taming',
+                                                                                      'pytorch_lightning')}
+    try:
+        import transformers
+        from transformers import CLIPTextConfig, CLIPTextModel
+        CLIPTextModel(CLIPTextConfig(num_hidden_layers=1, hidden_size=64, intermediate_size=64, num_attention_heads=1,
+                                     vocab_size=8))          # force the lazy sub-imports now
+    finally:
+        sys.modules.update(hidden)
+    from oracle import clip as oclip
+    c = oclip.SD_CLIP
+    m = CLIPTextModel(CLIPTextConfig(hidden_act='quick_gelu', attention_dropout=0.0, **c)).eval()
+    sd = m.state_dict()
+    inner = 'text_model.' if any(k.startswith('text_model.') for k in sd) else ''
+    new = {}
+    for k, v in sd.items():
+        name = oclip.PREFIX + k[len(inner):]
+        if 'position_ids' in k:
+            new[k] = v
+        else:
+            new[k] = torch.from_numpy(synth.make_tensor(name, tuple(v.shape)))
+    m.load_state_dict(new, strict=True)
+    ids = gi.clip_ids()
+    with torch.no_grad():
+        z = m(input_ids=ids).last_hidden_state
+    keys = {oclip.PREFIX + k[len(inner):]: list(v.shape) for k, v in sd.items() if 'position_ids' not in k}
+    with open(os.path.join(GOLD, 'clip_keys.json'), 'w') as f:
+        json.dump({'transformers_version': transformers.__version__, 'keys': keys}, f)
+    save('clip', z=z, ids=ids)
+
+
 # --------------------------------------------------------------------------- G3 per-op
 def g_ops():
     from ldm.modules.diffusionmodules.openaimodel import ResBlock, Downsample, Upsample
@@ -510,7 +545,7 @@ def g_sampler_unet():
 
 ALL = dict(schedule=g_schedule, ddpm_schedule=g_ddpm_schedule, param_keys=g_param_keys, ops=g_ops,
            unet_full=g_unet_full, controlnet_full=g_controlnet_full, small_nets=g_small_nets,
-           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet, vae=g_vae)
+           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip)
 
 
 def main():
