@@ -15,7 +15,7 @@ FLAG_USE_ORIGINAL = 1
 FLAG_ONLY_MID_CONTROL = 2
 FLAG_NO_CONTROL = 4
 
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_GEGLU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GEGLU, ACT_QGELU = 0, 1, 2, 3, 4
 OUT_F16, OUT_F32, OUT_F32_NCHW, OUT_F16_T = 0, 1, 2, 3
 
 
@@ -28,6 +28,8 @@ class FgdmConfig(C.Structure):
         ('n_controlnets', C.c_int32), ('hint_channels', C.c_int32), ('workspace_bytes', C.c_int64),
         ('vae_ch', C.c_int32), ('vae_n_levels', C.c_int32), ('vae_ch_mult', C.c_int32 * MAX_LEVELS),
         ('vae_num_res_blocks', C.c_int32), ('vae_z_channels', C.c_int32), ('vae_out_ch', C.c_int32),
+        ('clip_layers', C.c_int32), ('clip_width', C.c_int32), ('clip_heads', C.c_int32), ('clip_mlp', C.c_int32),
+        ('clip_vocab', C.c_int32), ('clip_max_len', C.c_int32),
         ('reserved_', C.c_int32),
     ]
 
@@ -48,6 +50,7 @@ SIGNATURES = {
     'fgdm_finalize_weights': (_i, [_p]),
     'fgdm_set_hint': (_i, [_p, _i, _p, _i, _i, _i, _p]),
     'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    'fgdm_clip_encode': (_i, [_p, _p, _i, _i, _p, _p]),
     'fgdm_vae_decode': (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
     'fgdm_image_to_uint8': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     'fgdm_resize_linear_uint8': (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),

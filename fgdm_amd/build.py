@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfgdm_hip.so')
-SOURCES = ['igemm.hip', 'igemm2.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'boundary.hip', 'engine.hip']
+SOURCES = ['igemm.hip', 'igemm2.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'boundary.hip', 'text.hip', 'engine.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable', '-ffp-contract=fast', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-fno-honor-nans']
 

@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------- implicit GEMM
 // out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),  m = (b, oy, ox) output pixel, k = (tap, cin)
 enum IgemmMode { IG_LINEAR = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP2 = 3 };
-enum IgemmAct { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3 };
+enum IgemmAct { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3, ACT_QGELU = 4 /* x * sigmoid(1.702 x), CLIP MLP */ };
 enum IgemmOut { OUT_F16 = 0, OUT_F32 = 1, OUT_F32_NCHW = 2, OUT_F16_T = 3 };
 
 struct IgemmArgs {
@@ -81,6 +81,12 @@ int softmax_rows(const float* S, half_t* P, int rows, int cols, hipStream_t s);
 int image_to_u8(const float* x, uint8_t* y, int B, int C, int HW, int mode, hipStream_t s);
 int resize_linear_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int u8_to_hint(const uint8_t* src, float* dst, int B, int HW, int C, hipStream_t s);
+int embed_tokens(const int64_t* ids, const half_t* tok, const half_t* pos, half_t* out, int rows, int T, int W, int vocab,
+                 hipStream_t s);
+int f16_to_f32(const half_t* x, float* y, size_t n, hipStream_t s);
+// causal / full attention over short sequences (T <= 128, d = 64) with q|k|v as column blocks of one matrix
+int small_attention_launch(const half_t* qkv, int ld, int koff, int voff, half_t* out, int ldo, int B, int heads, int T,
+                           int d, int causal, hipStream_t s);
 int transpose_pad_keys(const half_t* v, half_t* vt, int B, int Tk, int C, int Tkpad, hipStream_t s);
 // x_prev, pred_x0 from eps (with CFG combine when e_uncond != null); all fp32 NCHW
 int ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,

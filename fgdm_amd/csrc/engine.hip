@@ -145,6 +145,17 @@ struct Vae {
     float* pq = nullptr;                   // post_quant_conv: 16 weights [co][ci] + 4 biases
 };
 
+// CLIP text encoder (transformers.CLIPTextModel behind FrozenCLIPEmbedder; ldm/modules/encoders/modules.py:137-162)
+struct ClipLayer { std::string pre; NormW ln1, ln2; GemmW qkv, o, fc1, fc2; };
+struct Clip {
+    bool on = false, packed = false;
+    std::string prefix;
+    half_t* tok = nullptr;    // [vocab][W] fp16
+    half_t* pos = nullptr;    // [max_len][W] fp16
+    std::vector<ClipLayer> layers;
+    NormW final_ln;
+};
+
 static int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
 // Built-in kernel timer: when enabled, every launch is bracketed by HIP events recorded on the launch stream
@@ -192,6 +203,7 @@ struct Prof {
 
 }  // namespace
 
+#define CHK0(x) do { int _rc0 = (x); if (_rc0 != FGDM_OK) return _rc0; } while (0)
 struct fgdm_engine {
     fgdm_config cfg{};
     int device = -1;
@@ -202,6 +214,7 @@ struct fgdm_engine {
     Net unet;
     std::vector<Net> cns;
     Vae vae;
+    Clip clip;
     Arena arena;
     half_t* zero = nullptr;
     std::vector<void*> weight_allocs;
@@ -411,6 +424,30 @@ struct fgdm_engine {
         reg_wb(v.prefix + "post_quant_conv", {4, 4, 1, 1});
         return FGDM_OK;
     }
+    // CLIPTextModel state-dict keys in module-registration order, under the reference checkpoints' prefix
+    int build_clip() {
+        const int W = cfg.clip_width, I = cfg.clip_mlp;
+        if (cfg.clip_layers > 64 || (W & 63) || (I & 63) || cfg.clip_heads <= 0 || W != 64 * cfg.clip_heads ||
+            cfg.clip_vocab <= 0 || cfg.clip_max_len <= 0 || cfg.clip_max_len > 128)
+            return fail(FGDM_ERR_ARG, "unsupported text-encoder config (head dim must be 64, width/mlp multiples of 64, <= 128 tokens)");
+        Clip& c = clip;
+        c.on = true;
+        c.prefix = "cond_stage_model.transformer.text_model.";
+        reg(c.prefix + "embeddings.token_embedding.weight", {cfg.clip_vocab, W});
+        reg(c.prefix + "embeddings.position_embedding.weight", {cfg.clip_max_len, W});
+        c.layers.resize(cfg.clip_layers);
+        for (int i = 0; i < cfg.clip_layers; ++i) {
+            ClipLayer& l = c.layers[i];
+            l.pre = c.prefix + "encoder.layers." + std::to_string(i) + ".";
+            for (const char* n : {"k_proj", "v_proj", "q_proj", "out_proj"}) reg_wb(l.pre + "self_attn." + n, {W, W});
+            reg_wb(l.pre + "layer_norm1", {W});
+            reg_wb(l.pre + "mlp.fc1", {I, W});
+            reg_wb(l.pre + "mlp.fc2", {W, I});
+            reg_wb(l.pre + "layer_norm2", {W});
+        }
+        reg_wb(c.prefix + "final_layer_norm", {W});
+        return FGDM_OK;
+    }
     int build() {
         if (cfg.n_levels < 1 || cfg.n_levels > FGDM_MAX_LEVELS || cfg.model_channels <= 0 || (cfg.model_channels & 63) ||
             cfg.num_heads <= 0 || cfg.n_controlnets < 0 || cfg.n_controlnets > FGDM_MAX_CONTROLNETS ||
@@ -427,7 +464,8 @@ struct fgdm_engine {
         cns.resize(cfg.n_controlnets);
         for (int k = 0; k < cfg.n_controlnets; ++k)
             build_net(cns[k], k == 0 ? std::string("control_model.") : "control_model_" + std::to_string(k) + ".", true, 0);
-        if (cfg.vae_ch > 0) return build_vae();
+        if (cfg.vae_ch > 0) CHK0(build_vae());
+        if (cfg.clip_layers > 0) CHK0(build_clip());
         return FGDM_OK;
     }
 
@@ -646,6 +684,33 @@ struct fgdm_engine {
         for (auto& name : order)
             if (name.compare(0, v.prefix.size(), v.prefix) == 0) { auto& ps = params[name]; std::vector<float>().swap(ps.host); }
         v.packed = true;
+        return FGDM_OK;
+    }
+
+    int pack_clip() {
+        Clip& c = clip;
+        auto up16 = [&](const std::string& name, half_t** dst) -> int {
+            const ParamSlot* w = slot(name);
+            if (!w) return FGDM_ERR_STATE;
+            std::vector<half_t> h(w->host.size());
+            for (size_t i = 0; i < h.size(); ++i) h[i] = (half_t)w->host[i];
+            *dst = upload(h);
+            return *dst ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed");
+        };
+        CHK(up16(c.prefix + "embeddings.token_embedding.weight", &c.tok));
+        CHK(up16(c.prefix + "embeddings.position_embedding.weight", &c.pos));
+        for (ClipLayer& l : c.layers) {
+            CHK(pack_norm(l.ln1, l.pre + "layer_norm1"));
+            CHK(pack_norm(l.ln2, l.pre + "layer_norm2"));
+            CHK(pack_stack(l.qkv, {l.pre + "self_attn.q_proj", l.pre + "self_attn.k_proj", l.pre + "self_attn.v_proj"}, true));
+            CHK(pack_linear(l.o, l.pre + "self_attn.out_proj", true));
+            CHK(pack_linear(l.fc1, l.pre + "mlp.fc1", true));
+            CHK(pack_linear(l.fc2, l.pre + "mlp.fc2", true));
+        }
+        CHK(pack_norm(c.final_ln, c.prefix + "final_layer_norm"));
+        for (auto& name : order)
+            if (name.compare(0, c.prefix.size(), c.prefix) == 0) { auto& ps = params[name]; std::vector<float>().swap(ps.host); }
+        c.packed = true;
         return FGDM_OK;
     }
 
@@ -1079,6 +1144,40 @@ struct fgdm_engine {
         return FGDM_OK;
     }
 
+    // ------------------------------------------------------------------------------------ text encoder
+    // CLIPTextModel.forward -> last_hidden_state (pre-LN transformer, causal attention, quick-GELU MLP)
+    int clip_encode(const int64_t* ids, int B, int T, float* out) {
+        if (!clip.on) return fail(FGDM_ERR_STATE, "engine was created without a text encoder (clip_layers = 0)");
+        if (!clip.packed) return fail(FGDM_ERR_STATE, "weights not finalized");
+        if (B <= 0 || T <= 0 || T > cfg.clip_max_len) return fail(FGDM_ERR_ARG, "bad shape (T must be <= clip_max_len)");
+        const int W = cfg.clip_width, rows = B * T;
+        Tensor h = talloc(1, 1, rows, W), n, qkv, a, h2, f;
+        if (!h.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (embed_tokens(ids, clip.tok, clip.pos, h.p, rows, T, W, cfg.clip_vocab, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "embedding kernel");
+        for (const ClipLayer& l : clip.layers) {
+            CHK(lnorm(l.ln1, h, &n));
+            CHK(linear(l.qkv, n, Epi{}, &qkv));
+            tfree(n);
+            a = talloc(1, 1, rows, W);
+            if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (small_attention_launch(qkv.p, 3 * W, W, 2 * W, a.p, W, B, cfg.clip_heads, T, W / cfg.clip_heads, 1, s) != FGDM_OK)
+                return fail(FGDM_ERR_HIP, "text attention kernel");
+            tfree(qkv);
+            { Epi e; e.resid = h.p; e.ld_res = W; CHK(linear(l.o, a, e, &h2)); }
+            tfree(a); tfree(h);
+            CHK(lnorm(l.ln2, h2, &n));
+            { Epi e; e.act = ACT_QGELU; CHK(linear(l.fc1, n, e, &f)); }
+            tfree(n);
+            { Epi e; e.resid = h2.p; e.ld_res = W; CHK(linear(l.fc2, f, e, &h)); }
+            tfree(f); tfree(h2);
+        }
+        CHK(lnorm(clip.final_ln, h, &n));
+        tfree(h);
+        if (f16_to_f32(n.p, out, n.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
+        tfree(n);
+        return FGDM_OK;
+    }
+
     // ------------------------------------------------------------------------------------ first-stage decoder
     // ResnetBlock.forward with temb = None (model.py:121-141); Normalize = GroupNorm(32, eps 1e-6), swish = SiLU
     int vres_fwd(const VRes& r, const Tensor& x, Tensor* out) {
@@ -1317,6 +1416,7 @@ int fgdm_finalize_weights(fgdm_engine* e) {
     if (rc != FGDM_OK) return rc;
     for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }
     if (e->vae.on) { rc = e->pack_vae(); if (rc != FGDM_OK) return rc; }
+    if (e->clip.on) { rc = e->pack_clip(); if (rc != FGDM_OK) return rc; }
     e->finalized = true;
     return FGDM_OK;
 }
@@ -1384,6 +1484,12 @@ int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const flo
     if (!e || !x || (!t && !t_float) || !ctx || !eps_out) return FGDM_ERR_ARG;
     e->s = as_stream(stream);
     return e->apply_model(x, t, t_float, ctx, pcond, control_scales, B, H, W, flags, eps_out);
+}
+
+int fgdm_clip_encode(fgdm_engine* e, const int64_t* ids, int B, int T, float* out, void* stream) {
+    if (!e || !ids || !out) return FGDM_ERR_ARG;
+    e->s = as_stream(stream);
+    return e->clip_encode(ids, B, T, out);
 }
 
 int fgdm_vae_decode(fgdm_engine* e, const float* z, int B, int H, int W, float scale, float* image, void* stream) {

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
                     float x = acc[i][j][g * 4 + e] + bias + rvv[g * 4 + e];
                     if (a.act == ACT_SILU) x = silu_f(x);
                     else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (a.act == ACT_QGELU) x = x / (1.0f + __expf(-1.702f * x));
                     else if (geglu) {
                         if constexpr (NI >= 2) x = x * gelu_f(acc[i][j | 1][g * 4 + e] + gbias);
                     }
@@ -280,6 +281,7 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 63) || (a.C0 & 63) || (a.C1 & 63)) return FGDM_ERR_ARG;
     if (a.act == ACT_GEGLU && (a.N & 63)) return FGDM_ERR_ARG;
     int force = a.force_cfg ? a.force_cfg : g_force_cfg;
+    if (a.act == ACT_QGELU && force >= 4) force = 0;   // the pipelined kernel's epilogue does not carry quick-GELU
     if (a.splitk > 1) {        // split-K plan made by the caller (igemm_splitk_factor): 128x320 tiles + reduction pass
         if (!a.ws) return FGDM_ERR_ARG;
         const int rc = igemm2_launch(a, 2, s);

@@ -16,9 +16,15 @@ SD_V1 = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolu
 SD_VAE = dict(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=(), z_channels=4)
 
 
-def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, workspace_bytes=0, vae=None):
+# text tower of openai/clip-vit-large-patch14 (FrozenCLIPEmbedder's default `version`)
+SD_CLIP = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+               num_attention_heads=12, max_position_embeddings=77)
+
+
+def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, workspace_bytes=0, vae=None, clip=None):
     """fgdm_config from the reference's UNetModel kwargs (models/config.yaml:33-48); `vae`: None (no first-stage
-    decoder), True (SD_VAE) or the AutoencoderKL `ddconfig` dict."""
+    decoder), True (SD_VAE) or the AutoencoderKL `ddconfig` dict; `clip`: None, True (SD_CLIP) or a CLIPTextConfig-style
+    dict (text encoder in the engine)."""
     cfg = dict(SD_V1 if cfg is None else cfg)
     c = _lib.FgdmConfig()
     c.in_channels = cfg['in_channels']
@@ -50,6 +56,14 @@ def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, w
         c.vae_num_res_blocks = dd['num_res_blocks']
         c.vae_z_channels = dd['z_channels']
         c.vae_out_ch = dd['out_ch']
+    if clip:
+        cc = dict(SD_CLIP if clip is True else clip)
+        c.clip_layers = cc['num_hidden_layers']
+        c.clip_width = cc['hidden_size']
+        c.clip_heads = cc['num_attention_heads']
+        c.clip_mlp = cc['intermediate_size']
+        c.clip_vocab = cc['vocab_size']
+        c.clip_max_len = cc['max_position_embeddings']
     return c
 
 
@@ -82,12 +96,13 @@ def _ptr(t):
 class Engine:
     """One engine per device: owns packed weights + activation workspace in HBM."""
 
-    def __init__(self, cfg=None, use_adapter=False, n_controlnets=0, device=0, workspace_bytes=0, vae=None):
+    def __init__(self, cfg=None, use_adapter=False, n_controlnets=0, device=0, workspace_bytes=0, vae=None, clip=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('fgdm_amd.Engine needs a GPU (MI355X); there is no CPU fallback')
-        self.config = make_config(cfg, use_adapter, n_controlnets, workspace_bytes=workspace_bytes, vae=vae)
+        self.config = make_config(cfg, use_adapter, n_controlnets, workspace_bytes=workspace_bytes, vae=vae, clip=clip)
         self.has_vae = bool(vae)
+        self.has_clip = bool(clip)
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
         h = C.c_void_p()
@@ -194,6 +209,14 @@ class Engine:
                                        flags, _ptr(eps), _stream())
         self._check(rc, 'fgdm_apply_model')
         return eps
+
+    def clip_encode(self, ids):
+        """CLIPTextModel(input_ids=ids).last_hidden_state: int64 ids [B, T<=77] -> fp32 [B, T, 768] on the device."""
+        ids = torch.as_tensor(ids).to(self.device, torch.int64).contiguous()
+        B, T = ids.shape
+        out = torch.empty(B, T, self.config.clip_width, device=self.device, dtype=torch.float32)
+        self._check(self.lib.fgdm_clip_encode(self.h, _ptr(ids), B, T, _ptr(out), _stream()), 'fgdm_clip_encode')
+        return out
 
     def vae_decode(self, z, scale=1.0):
         """AutoencoderKL.decode(scale * z): fp32 NCHW latents [B,4,H,W] -> fp32 NCHW images [B,3,8H,8W]."""

@@ -9,8 +9,9 @@ They expose what the samplers and the inference scripts require of `model` (SURV
 alphas_cumprod(_prev), device, parameterization, apply_model, q_sample, control_scales, cuda()/to()/eval(),
 ema_scope(), load_state_dict().  All network arithmetic runs in the HIP engine; the per-step latent updates run
 in the sampler kernels.  decode_first_stage (ddpm.py:832-889) runs in the engine too when the
-model is built with a `first_stage_config`.  CLIP text encoding is outside this path: plug a callable in via
-`cond_stage_model`.
+model is built with a `first_stage_config`, and get_learned_conditioning (FrozenCLIPEmbedder's transformer,
+ldm/modules/encoders/modules.py:137-162) when it is built with a `cond_stage_config`; only the BPE
+tokenizer (host code of the third-party `transformers` package) stays outside: `model.tokenizer`.
 """
 import contextlib
 
@@ -49,14 +50,15 @@ class LatentDiffusion(_Buffers):
                  beta_schedule='linear', linear_start=0.00085, linear_end=0.012, cosine_s=8e-3, given_betas=None,
                  v_posterior=0.0, parameterization='eps', conditioning_key='crossattn', scale_factor=0.18215,
                  channels=4, image_size=32, log_every_t=200, clip_denoised=False, device=0, first_stage_config=None,
-                 **ignored):
+                 cond_stage_config=None, **ignored):
         if parameterization != 'eps':
             raise NotImplementedError('only eps-parameterization is used by the shipped configs (models/config.yaml)')
         if conditioning_key != 'crossattn':
             raise NotImplementedError("only conditioning_key='crossattn' is on the hot path (models/config.yaml:15)")
         self.engine = engine if engine is not None else _k.Engine(unet_config, use_adapter=use_adapter,
                                                                    n_controlnets=n_controlnets, device=device,
-                                                                   vae=self._ddconfig(first_stage_config))
+                                                                   vae=self._ddconfig(first_stage_config),
+                                                                   clip=self._clipconfig(cond_stage_config))
         self.device = self.engine.device
         self.model = DiffusionWrapper(self.engine, conditioning_key)
         self.parameterization = parameterization
@@ -67,7 +69,10 @@ class LatentDiffusion(_Buffers):
         self.log_every_t = log_every_t
         self.clip_denoised = clip_denoised
         self.shorten_cond_schedule = False
-        self.cond_stage_model = None        # callable(list[str]) -> [B,77,768]   (CLIP; out of scope here)
+        self.cond_stage_model = None        # optional callable(list[str]) -> [B,77,768] overriding the engine's text encoder
+        self.tokenizer = None               # callable(list[str]) -> int64 ids [B,77]; default: transformers.CLIPTokenizer
+        self.clip_version = 'openai/clip-vit-large-patch14'
+        self.max_length = 77
         self.first_stage_decode = None      # optional callable(z / scale_factor) -> image overriding the engine's decoder
         self._register_schedule(self.device, kind=beta_schedule, timesteps=timesteps, linear_start=linear_start,
                                 linear_end=linear_end, cosine_s=cosine_s, v_posterior=v_posterior,
@@ -86,6 +91,21 @@ class LatentDiffusion(_Buffers):
         if 'params' in fc:
             fc = dict(fc['params'])
         return dict(fc.get('ddconfig', fc))
+
+    @staticmethod
+    def _clipconfig(cond_stage_config):
+        """cond_stage_config as in models/config.yaml:73-74 ({'target': '...FrozenCLIPEmbedder'}), True (SD-v1 text tower),
+        a CLIPTextConfig-style dict, or None (no text encoder in the engine)."""
+        if not cond_stage_config:
+            return None
+        if cond_stage_config is True:
+            return True
+        cc = dict(cond_stage_config)
+        if 'target' in cc:
+            if not str(cc['target']).endswith('FrozenCLIPEmbedder'):
+                raise NotImplementedError(f"cond_stage_config target {cc['target']}: only FrozenCLIPEmbedder is shipped")
+            return True
+        return cc
 
     # ---- nn.Module-ish surface the scripts touch (scripts/txt2img_fgdm_inference.py:23-38,179-180,216-218)
     def cuda(self, *a, **k):
@@ -110,11 +130,30 @@ class LatentDiffusion(_Buffers):
             self._finalized = True
         return missing, unexpected
 
+    def _tokenize(self, text):
+        """FrozenCLIPEmbedder.forward's tokenizer call (modules.py:153-155)."""
+        if self.tokenizer is None:
+            try:
+                from transformers import CLIPTokenizer
+                tok = CLIPTokenizer.from_pretrained(self.clip_version)
+            except Exception as e:      # no vocabulary files on this machine (no network)
+                raise RuntimeError(f'CLIP tokenizer files for {self.clip_version} are not available ({e}); set '
+                                   'model.tokenizer to a callable list[str] -> int64 ids [B, 77]') from e
+            self.tokenizer = lambda t: tok(t, truncation=True, max_length=self.max_length, return_length=True,
+                                           return_overflowing_tokens=False, padding='max_length',
+                                           return_tensors='pt')['input_ids']
+        return self.tokenizer(text)
+
     def get_learned_conditioning(self, c):
-        if self.cond_stage_model is None:
-            raise NotImplementedError('text encoder (FrozenCLIPEmbedder) is outside the accelerated path; '
-                                      'set model.cond_stage_model to a callable returning [B,77,768]')
-        return self.cond_stage_model(c)
+        """ddpm.py get_learned_conditioning -> cond_stage_model.encode(c): list of prompts (or ready token ids) ->
+        [B, 77, 768]."""
+        if self.cond_stage_model is not None:
+            return self.cond_stage_model(c)
+        if not getattr(self.engine, 'has_clip', False):
+            raise NotImplementedError('this model was built without cond_stage_config; pass one (or set '
+                                      'model.cond_stage_model to a callable returning [B,77,768])')
+        ids = c if torch.is_tensor(c) or isinstance(c, np.ndarray) else self._tokenize(list(c))
+        return self.engine.clip_encode(ids)
 
     def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False, n=None):
         """ddpm.py:832-889 for an AutoencoderKL first stage: decode(z / scale_factor)."""

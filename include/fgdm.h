@@ -41,6 +41,10 @@ typedef struct fgdm_config {
     int32_t vae_ch, vae_n_levels;
     int32_t vae_ch_mult[FGDM_MAX_LEVELS];
     int32_t vae_num_res_blocks, vae_z_channels, vae_out_ch;
+    /* Text encoder (transformers.CLIPTextModel behind FrozenCLIPEmbedder, ldm/modules/encoders/modules.py:137-162);
+     * clip_layers = 0: engine without one.  openai/clip-vit-large-patch14: 12 layers, width 768, 12 heads, mlp 3072,
+     * vocab 49408, 77 positions. */
+    int32_t clip_layers, clip_width, clip_heads, clip_mlp, clip_vocab, clip_max_len;
     int32_t reserved_;
 } fgdm_config;
 
@@ -82,6 +86,11 @@ int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int 
 int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* t_float, const float* ctx,
                      const float* pcond, const float* control_scales, int B, int H, int W, int flags, float* eps_out,
                      void* stream);
+
+/* Text conditioning: FrozenCLIPEmbedder.forward after tokenisation (ldm/modules/encoders/modules.py:153-158):
+ * ids int64 [B, T] (device; T <= clip_max_len, the tokenizer's padded max_length) -> last_hidden_state fp32 [B, T, W]
+ * (device).  Needs clip_layers > 0 and the cond_stage_model.transformer.text_model.* tensors loaded. */
+int fgdm_clip_encode(fgdm_engine* e, const int64_t* ids, int B, int T, float* out, void* stream);
 
 /* First-stage decode: LatentDiffusion.decode_first_stage (ldm/models/diffusion/ddpm.py:832-889, plain branch) =
  * AutoencoderKL.decode(scale * z) (ldm/models/autoencoder.py:330-333; Decoder.forward,

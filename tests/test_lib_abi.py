@@ -64,6 +64,13 @@ def test_param_table_matches_reference_keys(lib):
     assert list(vae.keys()) == list(ref['vae_decoder'].keys())
     assert all(tuple(ref['vae_decoder'][k]) == v for k, v in vae.items())
     assert list(got.keys())[-len(vae):] == list(vae.keys())
+    # text-encoder keys (transformers.CLIPTextModel under the checkpoints' prefix) come last
+    got = eng.param_shapes(eng.make_config(gi.SD_CFG, vae=True, clip=True))
+    ck = json.load(open(os.path.join(GOLD, 'clip_keys.json')))['keys']
+    clip = {k: v for k, v in got.items() if k.startswith('cond_stage_model.')}
+    assert list(clip.keys()) == list(ck.keys())
+    assert all(tuple(ck[k]) == v for k, v in clip.items())
+    assert list(got.keys())[-len(clip):] == list(clip.keys())
     # several ControlNets get distinct prefixes
     got = eng.param_shapes(eng.make_config(gi.SD_CFG, n_controlnets=3))
     assert any(k.startswith('control_model_1.') for k in got) and any(k.startswith('control_model_2.') for k in got)
@@ -77,6 +84,8 @@ def test_unsupported_configs_are_rejected(lib):
         eng.make_config(gi.SD_CFG, vae=dict(eng.SD_VAE, attn_resolutions=[32]))
     with pytest.raises(ValueError):                     # decoder width must be a multiple of 64
         eng.param_shapes(eng.make_config(gi.SD_CFG, vae=dict(eng.SD_VAE, ch=96)))
+    with pytest.raises(ValueError):                     # text encoder: head dim must be 64
+        eng.param_shapes(eng.make_config(gi.SD_CFG, clip=dict(eng.SD_CLIP, num_attention_heads=8)))
     with pytest.raises(ValueError):                     # adapter needs the SD-v1 topology
         eng.param_shapes(eng.make_config(gi.SMALL_CFG, use_adapter=True))
 
