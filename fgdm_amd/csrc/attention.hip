@@ -15,7 +15,10 @@
 //     the fp16 probabilities used in the numerator -- and is rescaled together with O for free;
 //   * deferred-max rescale: the running max is only raised (and O rescaled) when some query of the wave exceeds it
 //     by more than 2^8; p <= 256 stays exact-range in fp16 and the final division by l cancels the offset;
-//   * K / Vt tiles are double-buffered in LDS and prefetched into registers one tile ahead (one barrier per tile).
+//   * K / Vt tiles are double-buffered in LDS and prefetched into registers one tile ahead (one barrier per tile);
+//   * d = 40 (padded to 48 in the contraction) has spare k slots: Q is pre-multiplied by log2(e) d^-1/2 and slot 40
+//     carries K = 1, Q = -m (the running max, kept fp16-representable), so the MFMA itself delivers
+//     s log2(e) d^-1/2 - m and the per-score work shrinks to max3 + exp2 + pack (FOLD).
 #include "common.h"
 
 #define ATT_THR 8.0f
@@ -30,6 +33,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     constexpr int NKS = DP / 16;
     constexpr int DT = (D + 31) / 32;         // 32-row tiles of O^T
     constexpr bool ONES = (DT * 32 > D);      // a spare O^T row exists: row D carries the softmax denominator
+    constexpr bool FOLD = (DP > D) && (D % 8 == 0);   // a spare contraction slot exists: scale and -max ride on the MFMA
+    constexpr int PS = D / 16, PH = (D % 16) / 8;     // fragment / lane half that hold contraction slot D (element 0)
     constexpr int KS = DP * 2 + 16;           // K-tile row stride in bytes: odd multiple of 16 -> b128 conflict-free
     constexpr int VS = 64 * 2 + 8;            // Vt-tile row stride in bytes: 34 dwords -> b64 conflict-free
     constexpr int DC = D / 8;                 // 16-byte chunks per K row
@@ -61,7 +66,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         if constexpr (DP > D) {
             for (int i = tid; i < 64 * (DP - D) / 8; i += 256) {
                 const int key = i / ((DP - D) / 8), c = i % ((DP - D) / 8);
-                *(h8*)(Ksb + key * KS + (D + c * 8) * 2) = (h8)(half_t)0;
+                h8 pad = (h8)(half_t)0;
+                if (FOLD && c == 0) pad[0] = (half_t)1;      // K[key][D] = 1: multiplies the -max kept in Q[q][D]
+                *(h8*)(Ksb + key * KS + (D + c * 8) * 2) = pad;
             }
         }
         for (int i = tid; i < (DT * 32 - D) * 16; i += 256) {
@@ -77,6 +84,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         const int c = 16 * s + 8 * lh;
         qf[s] = (h8)(half_t)0;
         if (c < D && q < T) qf[s] = *(const h8*)(Q + ((size_t)b * T + q) * ldq + head * D + c);
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = (half_t)((float)qf[s][j] * sl2e);
+        }
     }
 
     f32x16 oacc[DT];
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;   // l_run only used when there is no spare row (D = 160)
+    float m_run = FOLD ? 0.f : -INFINITY, l_run = 0.f;   // l_run only used when there is no spare row (D = 160)
 
     const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
     const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
@@ -159,6 +170,35 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
                 }
         }
         // ---- online softmax for this lane's query (keys split over the two lane halves), log2 domain
+        float psum = 0.f;
+        if constexpr (FOLD) {
+            // scores arrive as s log2(e) d^-1/2 - m_run; mx is therefore relative to the running max
+            float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const bool first = (k0 == 0);
+            if (first || !__all(mx <= ATT_THR)) {
+                const float m_new = first ? mx : m_run + fmaxf(mx, 0.f);
+                const float m_hat = (float)(half_t)m_new;          // the offset must be exactly what Q[q][D] can hold
+                const float delta = m_run - m_hat;
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(delta);
+                m_run = m_hat;
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[sub][r] += delta;   // this tile was taken against the old offset
+                if (lh == PH) qf[PS][0] = (half_t)(-m_hat);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[sub][r] = __builtin_amdgcn_exp2f(sacc[sub][r]);
+        } else {
         float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
@@ -174,7 +214,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
         }
-        float psum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -183,6 +222,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
                 sacc[sub][r] = p;
                 if constexpr (!ONES) psum += p;
             }
+        }
         if constexpr (!ONES) l_run += psum;
 
         // ---- O^T += Vt P^T   (with ONES: row D of O^T accumulates sum_k p)
