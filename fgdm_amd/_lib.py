@@ -49,6 +49,7 @@ SIGNATURES = {
     'fgdm_load_tensor': (_i, [_p, C.c_char_p, _p, _i, C.POINTER(_i64), _i]),
     'fgdm_finalize_weights': (_i, [_p]),
     'fgdm_set_hint': (_i, [_p, _i, _p, _i, _i, _i, _p]),
+    'fgdm_set_context': (_i, [_p, _p, _i, _p]),
     'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     'fgdm_clip_encode': (_i, [_p, _p, _i, _i, _p, _p]),
     'fgdm_vae_decode': (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),

@@ -215,6 +215,10 @@ struct fgdm_engine {
     std::vector<Net> cns;
     Vae vae;
     Clip clip;
+    // cross-attention K / V^T of a registered context (fgdm_set_context): constant over the denoising steps
+    struct CtxKV { Tensor k, vt; };
+    std::unordered_map<const Layer*, CtxKV> ctx_cache;
+    int ctx_B = 0, ctx_T = 0;
     Arena arena;
     half_t* zero = nullptr;
     std::vector<void*> weight_allocs;
@@ -860,6 +864,57 @@ struct fgdm_engine {
         return FGDM_OK;
     }
 
+    // attn2's k = to_k(context), v = to_v(context) (attention.py:183-186); V is produced transposed for the kernel.
+    // persistent = true: buffers come from hipMalloc and live in ctx_cache until the next set_context
+    int cross_kv(const Layer& l, const Tensor& ctx16, bool persistent, Tensor* k2, Tensor* v2t) {
+        const int B = ctx16.B, C = l.cin, Tk = ctx16.H * ctx16.W, Tkp = roundup(Tk, 64);
+        if (persistent) {
+            k2->B = B; k2->H = ctx16.H; k2->W = ctx16.W; k2->C = C;
+            v2t->B = B; v2t->H = 1; v2t->W = C; v2t->C = Tkp;
+            if (hipMalloc(&k2->p, k2->numel() * sizeof(half_t)) != hipSuccess ||
+                hipMalloc(&v2t->p, v2t->numel() * sizeof(half_t)) != hipSuccess) return fail(FGDM_ERR_NOMEM, "hipMalloc (context cache)");
+            { Epi e; e.out = k2->p; e.ld_out = C; CHK(linear(l.k2, ctx16, e, nullptr)); }
+        } else {
+            CHK(linear(l.k2, ctx16, Epi{}, k2));
+            *v2t = talloc(B, 1, C, Tkp);
+            if (!v2t->p) return fail(FGDM_ERR_NOMEM, "workspace");
+        }
+        if (Tkp != Tk) HIP_TRY(hipMemsetAsync(v2t->p, 0, v2t->numel() * sizeof(half_t), s));
+        { Epi e; e.out_kind = OUT_F16_T; e.out = v2t->p; e.ld_out = Tkp; e.rps = Tk; CHK(linear(l.v2, ctx16, e, nullptr)); }
+        return FGDM_OK;
+    }
+    void drop_context() {
+        for (auto& kv : ctx_cache) { (void)hipFree(kv.second.k.p); (void)hipFree(kv.second.vt.p); }
+        ctx_cache.clear();
+        ctx_B = 0;
+    }
+    // The conditioning is the same tensor in every denoising step (ddim.py:147-162 passes `cond` unchanged): project it
+    // through every cross-attention layer's to_k / to_v once; apply_model(ctx = NULL) then reuses the projections.
+    int set_context(const float* ctx, int B) {
+        if (!finalized) return fail(FGDM_ERR_STATE, "weights not finalized");
+        if (B <= 0) return fail(FGDM_ERR_ARG, "bad shape");
+        drop_context();
+        Tensor ctx16 = talloc(B, 1, 77, cfg.context_dim);
+        if (!ctx16.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
+        auto walk = [&](const Block& blk) -> int {
+            for (const Layer& l : blk)
+                if (l.type == L_ATTN) { CtxKV kv; CHK(cross_kv(l, ctx16, true, &kv.k, &kv.vt)); ctx_cache[&l] = kv; }
+            return FGDM_OK;
+        };
+        auto walk_net = [&](const Net& n) -> int {
+            for (auto& b : n.input) CHK(walk(b));
+            CHK(walk(n.middle));
+            for (auto& b : n.output) CHK(walk(b));
+            return FGDM_OK;
+        };
+        CHK(walk_net(unet));
+        for (auto& n : cns) CHK(walk_net(n));
+        tfree(ctx16);
+        ctx_B = B; ctx_T = 77;
+        return FGDM_OK;
+    }
+
     // SpatialTransformer.forward with one BasicTransformerBlock (attention.py:234-292)
     int attn_fwd(const Layer& l, const Tensor& x, const Tensor& ctx16, Tensor* out) {
         const int B = x.B, T = x.H * x.W, C = x.C, d = C / l.heads;
@@ -890,12 +945,17 @@ struct fgdm_engine {
         CHK(lnorm(l.ln2, h2, &n));
         CHK(linear(l.q2, n, Epi{}, &q2));
         tfree(n);
-        const int Tk = ctx16.H * ctx16.W, Tkp = roundup(Tk, 64);
-        CHK(linear(l.k2, ctx16, Epi{}, &k2));
-        v2t = talloc(B, 1, C, Tkp);
-        if (!v2t.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        if (Tkp != Tk) HIP_TRY(hipMemsetAsync(v2t.p, 0, v2t.numel() * sizeof(half_t), s));
-        { Epi e; e.out_kind = OUT_F16_T; e.out = v2t.p; e.ld_out = Tkp; e.rps = Tk; CHK(linear(l.v2, ctx16, e, nullptr)); }
+        int Tk, Tkp;
+        const bool cached = (ctx16.p == nullptr);
+        if (cached) {      // K / V^T were projected once by set_context
+            auto it = ctx_cache.find(&l);
+            if (it == ctx_cache.end() || ctx_B != B) return fail(FGDM_ERR_STATE, "no cached context for this batch (fgdm_set_context)");
+            k2 = it->second.k; v2t = it->second.vt;
+            Tk = ctx_T; Tkp = roundup(Tk, 64);
+        } else {
+            Tk = ctx16.H * ctx16.W; Tkp = roundup(Tk, 64);
+            CHK(cross_kv(l, ctx16, false, &k2, &v2t));
+        }
         a = talloc(B, x.H, x.W, C);
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
         { char tag[56]; snprintf(tag, sizeof(tag), "attn B%d T%d Tk%d d%d", B, T, Tk, d);
@@ -903,7 +963,8 @@ struct fgdm_engine {
           int rc = attention_launch(q2.p, C, k2.p, C, v2t.p, Tkp, a.p, C, B, l.heads, T, Tk, d, s);
           prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed"); }
-        tfree(q2); tfree(k2); tfree(v2t);
+        tfree(q2);
+        if (!cached) { tfree(k2); tfree(v2t); }
         { Epi e; e.resid = h2.p; e.ld_res = C; CHK(linear(l.o2, a, e, &h)); }
         tfree(a); tfree(h2);
         // --- GEGLU feed-forward
@@ -1078,10 +1139,12 @@ struct fgdm_engine {
         if (B <= 0 || H <= 0 || W <= 0) return fail(FGDM_ERR_ARG, "bad shape");
         Net& n = unet;
         const int HW = H * W;
-        Tensor x4 = talloc(B, H, W, 4), ctx16 = talloc(B, 1, 77, cfg.context_dim);
-        if (!x4.p || !ctx16.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        Tensor x4 = talloc(B, H, W, 4), ctx16;
+        if (ctx) ctx16 = talloc(B, 1, 77, cfg.context_dim);
+        else if (ctx_B != B) return fail(FGDM_ERR_STATE, "ctx is NULL but no context of this batch size was registered (fgdm_set_context)");
+        if (!x4.p || (ctx && !ctx16.p)) return fail(FGDM_ERR_NOMEM, "workspace");
         if (nchw_f32_to_nhwc_f16(x, x4.p, B, 4, HW, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
-        if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
+        if (ctx && f32_to_f16(ctx, ctx16.p, ctx16.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
         float* emb = nullptr;
         CHK(embed(n, t, tf, B, &emb));
         EmbCtx ec{emb, n.emb_total};
@@ -1139,7 +1202,8 @@ struct fgdm_engine {
         tfree(h);
         { Epi e; e.out_kind = OUT_F32_NCHW; e.out = eps_out; e.ld_out = HW; CHK(conv3(n.out_conv, g, nullptr, 1, false, e, nullptr)); }
         tfree(g);
-        tfree(x4); tfree(ctx16);
+        tfree(x4);
+        if (ctx16.p) tfree(ctx16);
         arena.release(emb);
         return FGDM_OK;
     }
@@ -1352,6 +1416,7 @@ void fgdm_destroy(fgdm_engine* e) {
     for (void* p : e->weight_allocs) (void)hipFree(p);
     if (e->zero) (void)hipFree(e->zero);
     for (auto& n : e->cns) if (n.guided.p) (void)hipFree(n.guided.p);
+    e->drop_context();
     delete e;
 }
 
@@ -1412,6 +1477,7 @@ int fgdm_finalize_weights(fgdm_engine* e) {
     if (!e) return FGDM_ERR_ARG;
     int rc = e->ensure_device();
     if (rc != FGDM_OK) return rc;
+    e->drop_context();
     rc = e->pack_net(e->unet);
     if (rc != FGDM_OK) return rc;
     for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }
@@ -1481,9 +1547,15 @@ int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int 
 int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* t_float, const float* ctx,
                      const float* pcond, const float* control_scales, int B, int H, int W, int flags, float* eps_out,
                      void* stream) {
-    if (!e || !x || (!t && !t_float) || !ctx || !eps_out) return FGDM_ERR_ARG;
+    if (!e || !x || (!t && !t_float) || !eps_out) return FGDM_ERR_ARG;
     e->s = as_stream(stream);
     return e->apply_model(x, t, t_float, ctx, pcond, control_scales, B, H, W, flags, eps_out);
+}
+
+int fgdm_set_context(fgdm_engine* e, const float* ctx, int B, void* stream) {
+    if (!e || !ctx) return FGDM_ERR_ARG;
+    e->s = as_stream(stream);
+    return e->set_context(ctx, B);
 }
 
 int fgdm_clip_encode(fgdm_engine* e, const int64_t* ids, int B, int T, float* out, void* stream) {

@@ -82,7 +82,7 @@ class _SamplerBase:
         if uc is None or scale == 1.:
             return self.model.apply_model(x, t, c, **kwargs), None
         x_in, t_in = torch.cat([x] * 2), torch.cat([t] * 2)
-        c_in = self._cat_cond(uc, c)
+        c_in = self._batched_cond(uc, c)
         if c_in is None:        # conditionings that cannot share one batch: two calls (ddim_hacked.py:190-191)
             return self.model.apply_model(x, t, c, **kwargs), self.model.apply_model(x, t, uc, **kwargs)
         e_u, e_c = self.model.apply_model(x_in, t_in, c_in, **kwargs).chunk(2)
@@ -91,6 +91,31 @@ class _SamplerBase:
     @staticmethod
     def _cat_cond(uc, c):
         return torch.cat([uc, c])
+
+    @staticmethod
+    def _leaves(c, out):
+        if torch.is_tensor(c):
+            out.append(c)
+        elif isinstance(c, dict):
+            for k in sorted(c):
+                _SamplerBase._leaves(c[k], out)
+        elif isinstance(c, (list, tuple)):
+            for v in c:
+                _SamplerBase._leaves(v, out)
+        return out
+
+    def _batched_cond(self, uc, c):
+        """cat([uc, c]) is loop-invariant: build it once per (uc, c) pair and hand the SAME tensor object to every step,
+        so the engine can keep the context's K/V projections (Engine.apply_model).  The memo holds the source tensors, so
+        their ids cannot be recycled, and is invalidated by any in-place modification (_version)."""
+        leaves = self._leaves(uc, []) + self._leaves(c, [])
+        key = tuple((id(t), t._version) for t in leaves)
+        memo = getattr(self, '_cin_memo', None)
+        if memo is not None and memo[0] == key:
+            return memo[2]
+        c_in = self._cat_cond(uc, c)
+        self._cin_memo = (key, leaves, c_in)
+        return c_in
 
     def _x_prev(self, x, e_cond, e_uncond, scale, index, tabs, temperature, noise_dropout, repeat_noise,
                 want_pred_x0=True):

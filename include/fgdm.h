@@ -82,7 +82,13 @@ int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int 
  * eps = UNet(x, t, ctx, control = sum_k scales_k * ControlNet_k(x, hint_k, t, ctx)).
  * control_scales: n_controlnets * 13 floats (cldm.py:823) or NULL for 1.0.  pcond: optional adapter input
  * (openaimodel.py:838-841) fp32 NCHW or NULL (= x).  Timesteps: int64 `t`, or fractional fp32 `t_float` when non-NULL
- * (timestep_embedding accepts fractional t, util.py:165; DPM-Solver feeds (t_continuous - 1/N) * 1000). */
+ * (timestep_embedding accepts fractional t, util.py:165; DPM-Solver feeds (t_continuous - 1/N) * 1000).
+ * ctx: fp32 [B,77,context_dim], or NULL to use the context registered with fgdm_set_context. */
+/* The conditioning is loop-invariant (ddim.py:147-162 hands the same `cond` to every step): fgdm_set_context projects
+ * ctx fp32 [B,77,context_dim] (device) through every cross-attention layer's to_k / to_v (attention.py:183-186) once;
+ * fgdm_apply_model calls with ctx == NULL and the same B then reuse those projections.  A later fgdm_set_context or
+ * fgdm_finalize_weights replaces / drops them. */
+int fgdm_set_context(fgdm_engine* e, const float* ctx, int B, void* stream);
 int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* t_float, const float* ctx,
                      const float* pcond, const float* control_scales, int B, int H, int W, int flags, float* eps_out,
                      void* stream);

@@ -189,3 +189,29 @@ def test_fractional_timesteps(small_engine):
     p = params(arch.unet_param_shapes(gi.SMALL_CFG, adapter=False), 'small.')
     want = onn.unet_forward(p, gi.SMALL_CFG, x, tf, ctx, prefix='small.')
     assert report('UNet at fractional timesteps vs oracle', relerr(got, want), NET_TOL) < NET_TOL
+
+
+def test_context_cache_is_exact_and_invalidated(small_engine):
+    """fgdm_set_context: K/V projections of a registered context are reused across calls.  Results are bit-identical
+    to passing the context every time, and an in-place change of the context tensor is noticed."""
+    from fgdm_amd import _lib
+    e = small_engine
+    x = gi.get('small/x')[:, :, :16, :16].contiguous().cuda()
+    t = torch.tensor([981, 1]).cuda()
+    ctx = gi.get('small/ctx').cuda()
+    flags = _lib.FLAG_NO_CONTROL
+    e.cache_context = False
+    want = e.apply_model(x, t, ctx, flags=flags).clone()
+    e.cache_context = True
+    a = e.apply_model(x, t, ctx, flags=flags).clone()      # registers the context
+    b = e.apply_model(x, t, ctx, flags=flags).clone()      # served from the cached projections
+    assert torch.equal(a, want) and torch.equal(b, want)
+    ctx.mul_(0.5)                                          # in-place: must be re-projected
+    c = e.apply_model(x, t, ctx, flags=flags)
+    e.cache_context = False
+    assert torch.equal(c, e.apply_model(x, t, ctx, flags=flags))
+    assert not torch.equal(c, want)
+    e.cache_context = True
+    # a context of another batch size replaces the cache
+    d = e.apply_model(x[:1], t[:1], ctx[:1].contiguous(), flags=flags)
+    assert torch.equal(d[0], c[0])

@@ -186,3 +186,37 @@ def test_dpm_solver_and_ddim_encode(stubs):
     hint = gi.hint(2, 64, 48)
     enc, _ = smp.encode(x0, {'c_concat': [hint], 'c_crossattn': [c]}, 15)
     assert relerr(enc, g['encode_plain']) < STOL
+
+
+def test_batched_conditioning_is_built_once_per_sample(stubs):
+    """cat([uc, c]) is loop-invariant: every step must hand the SAME tensor object to apply_model (the engine keeps the
+    context's K/V projections keyed on that object), and an in-place change of a source tensor must invalidate it."""
+    x_T, c, uc = gi.get('samp/x_T'), gi.get('samp/c'), gi.get('samp/uc')
+    seen = []
+
+    class M(AnalyticLDM):
+        def apply_model(self, x, t, cc, **kw):
+            seen.append(cc)
+            return analytic_eps(x, t, cc)
+    smp = samplers.DDIMSampler(M())
+    smp.sample(S=5, batch_size=2, shape=[4, 8, 8], conditioning=c, verbose=False, unconditional_guidance_scale=7.5,
+               unconditional_conditioning=uc, x_T=x_T)
+    assert len(seen) == 5 and all(s is seen[0] for s in seen)
+    assert torch.equal(seen[0], torch.cat([uc, c]))
+    first = seen[0]
+    c.mul_(1.0)                       # in-place write: same values, new _version
+    smp.sample(S=2, batch_size=2, shape=[4, 8, 8], conditioning=c, verbose=False, unconditional_guidance_scale=7.5,
+               unconditional_conditioning=uc, x_T=x_T)
+    assert seen[5] is not first and seen[6] is seen[5]
+    # dict conditionings (ControlNet sampler): the concatenated cross-attention tensor is reused as well
+    hint = gi.hint(2, 64, 48)
+    seen.clear()
+
+    class MC(AnalyticLDM):
+        def apply_model(self, x, t, cc, **kw):
+            seen.append(cc['c_crossattn'][0])
+            return analytic_eps(x, t, {'c_concat': [torch.cat([hint, hint])], 'c_crossattn': cc['c_crossattn']})
+    smp = samplers.ControlDDIMSampler(MC())
+    smp.sample(4, 2, (4, 8, 8), {'c_concat': [hint], 'c_crossattn': [c]}, verbose=False, x_T=x_T,
+               unconditional_guidance_scale=9.0, unconditional_conditioning={'c_concat': [hint], 'c_crossattn': [uc]})
+    assert len(seen) == 4 and all(s is seen[0] for s in seen)
