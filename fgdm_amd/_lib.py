@@ -30,7 +30,7 @@ class FgdmConfig(C.Structure):
         ('vae_num_res_blocks', C.c_int32), ('vae_z_channels', C.c_int32), ('vae_out_ch', C.c_int32),
         ('clip_layers', C.c_int32), ('clip_width', C.c_int32), ('clip_heads', C.c_int32), ('clip_mlp', C.c_int32),
         ('clip_vocab', C.c_int32), ('clip_max_len', C.c_int32),
-        ('reserved_', C.c_int32),
+        ('n_extra_adapters', C.c_int32),
     ]
 
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     'fgdm_load_tensor': (_i, [_p, C.c_char_p, _p, _i, C.POINTER(_i64), _i]),
     'fgdm_finalize_weights': (_i, [_p]),
     'fgdm_set_hint': (_i, [_p, _i, _p, _i, _i, _i, _p]),
+    'fgdm_set_adapter_conds': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgdm_set_context': (_i, [_p, _p, _i, _p]),
     'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     'fgdm_clip_encode': (_i, [_p, _p, _i, _i, _p, _p]),

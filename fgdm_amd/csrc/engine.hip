@@ -122,6 +122,10 @@ struct Net {
     NormW out_gn; GemmW out_conv;                          // UNet only
     bool has_adapter = false;                              // UNet only
     GemmW ad_conv_in; std::vector<AdapterBlk> ad_body;
+    // AdaptUNetModel (openaimodel.py:993-999): num_prompts - 1 further Adapters over extra condition images; their
+    // features do not depend on x or t, so their sum is computed once per set of conds (fgdm_set_adapter_conds)
+    std::vector<GemmW> xad_conv_in; std::vector<std::vector<AdapterBlk>> xad_body;
+    Tensor xad_sum[4]; bool xad_valid = false;
     bool time_adapter = false; Block tad_body;             // TimeAdapter: time-conditioned ResBlocks (adapter.py:387-417)
     std::vector<GemmW> zero_convs; GemmW mid_out;          // ControlNet only
     std::vector<int> zero_ch;
@@ -307,6 +311,24 @@ struct fgdm_engine {
                     n.ad_body.push_back(b);
                 }
             reg_wb(ap + "conv_in", {chs[0], cfg.in_channels, 3, 3});
+            const int nx = control ? 0 : cfg.n_extra_adapters;
+            n.xad_conv_in.resize(nx); n.xad_body.resize(nx);
+            for (int kk = 0; kk < nx; ++kk) {
+                const std::string xp = prefix + "adapters." + std::to_string(kk) + ".";
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        AdapterBlk b;
+                        b.down = (i != 0 && j == 0);
+                        b.ic = b.down ? chs[i - 1] : chs[i];
+                        b.oc = chs[i];
+                        b.pre = xp + "body." + std::to_string(i * 2 + j) + ".";
+                        if (b.ic != b.oc) reg_wb(b.pre + "in_conv", {b.oc, b.ic, 1, 1});
+                        reg_wb(b.pre + "block1", {b.oc, b.oc, 3, 3});
+                        reg_wb(b.pre + "block2", {b.oc, b.oc, 1, 1});
+                        n.xad_body[kk].push_back(b);
+                    }
+                reg_wb(xp + "conv_in", {chs[0], cfg.in_channels, 3, 3});
+            }
         }
         if (n.time_adapter) {   // TimeAdapter(cin, [320,640,1280,1280], nums_rb=2, use_conv=False): openaimodel.py:554
             static const int chs[4] = {320, 640, 1280, 1280};
@@ -464,6 +486,8 @@ struct fgdm_engine {
         if (cfg.use_adapter && !(cfg.model_channels == 320 && cfg.n_levels == 4 && cfg.num_res_blocks == 2))
             return fail(FGDM_ERR_ARG, "FG-DM adapter requires the SD-v1 topology (openaimodel.py:554-556,855-859)");
         if (cfg.use_adapter < 0 || cfg.use_adapter > 2) return fail(FGDM_ERR_ARG, "use_adapter: 0 none, 1 Adapter, 2 TimeAdapter");
+        if (cfg.n_extra_adapters < 0 || cfg.n_extra_adapters > 7 || (cfg.n_extra_adapters && cfg.use_adapter != 1))
+            return fail(FGDM_ERR_ARG, "n_extra_adapters (AdaptUNetModel num_prompts - 1) needs use_adapter = 1");
         build_net(unet, "model.diffusion_model.", false, cfg.use_adapter);
         cns.resize(cfg.n_controlnets);
         for (int k = 0; k < cfg.n_controlnets; ++k)
@@ -638,6 +662,14 @@ struct fgdm_engine {
                     if (b.ic != b.oc) CHK(pack_linear(b.in_conv, b.pre + "in_conv", true));
                     CHK(pack_conv3(b.b1, b.pre + "block1"));
                     CHK(pack_linear(b.b2, b.pre + "block2", true));
+                }
+                for (size_t kk = 0; kk < n.xad_body.size(); ++kk) {
+                    CHK(pack_conv3(n.xad_conv_in[kk], n.prefix + "adapters." + std::to_string(kk) + ".conv_in"));
+                    for (auto& b : n.xad_body[kk]) {
+                        if (b.ic != b.oc) CHK(pack_linear(b.in_conv, b.pre + "in_conv", true));
+                        CHK(pack_conv3(b.b1, b.pre + "block1"));
+                        CHK(pack_linear(b.b2, b.pre + "block2", true));
+                    }
                 }
             }
         } else {
@@ -1019,15 +1051,16 @@ struct fgdm_engine {
 
     // Adapter.forward (adapter.py:334-346): four feature maps from the (noisy) latent itself.
     // ResnetBlock (adapter.py:301-313, ksize=1, sk=True): [AvgPool2d(2)] -> [conv1x1] -> conv3x3 -> ReLU -> conv1x1 -> +x
-    int adapter_fwd(Net& n, const Tensor& x4, Tensor feats[4]) {
+    int adapter_fwd(Net& n, const Tensor& x4, Tensor feats[4]) { return adapter_run(n.ad_conv_in, n.ad_body, x4, feats); }
+    int adapter_run(const GemmW& conv_in, const std::vector<AdapterBlk>& body, const Tensor& x4, Tensor feats[4]) {
         Tensor cur;
-        CHK(conv3(n.ad_conv_in, x4, nullptr, 1, false, Epi{}, &cur));
+        CHK(conv3(conv_in, x4, nullptr, 1, false, Epi{}, &cur));
         auto drop = [&](Tensor& t) {   // free a temporary unless it is one of the returned features
             for (int f = 0; f < 4; ++f) if (feats[f].p == t.p) return;
             tfree(t);
         };
-        for (size_t k = 0; k < n.ad_body.size(); ++k) {
-            const AdapterBlk& b = n.ad_body[k];
+        for (size_t k = 0; k < body.size(); ++k) {
+            const AdapterBlk& b = body[k];
             if (b.down) {
                 Tensor p = talloc(cur.B, cur.H / 2, cur.W / 2, cur.C);
                 if (!p.p) return fail(FGDM_ERR_NOMEM, "workspace");
@@ -1045,6 +1078,40 @@ struct fgdm_engine {
             cur = y;
             if (k % 2 == 1) feats[k / 2] = cur;   // nums_rb = 2: a feature after every second block
         }
+        return FGDM_OK;
+    }
+
+    void drop_adapter_conds() {
+        for (Tensor& t : unet.xad_sum) { if (t.p) (void)hipFree(t.p); t = Tensor{}; }
+        unet.xad_valid = false;
+    }
+    // AdaptUNetModel.forward's `conds` (openaimodel.py:1288-1291,1301-1305): sum_k adapters[k](conds[k]), kept until replaced
+    int set_adapter_conds(const float* const* conds, int nc, int B, int H, int W) {
+        if (!finalized) return fail(FGDM_ERR_STATE, "weights not finalized");
+        Net& n = unet;
+        drop_adapter_conds();
+        if (nc == 0) return FGDM_OK;
+        if (nc < 0 || nc > (int)n.xad_body.size() || !conds) return fail(FGDM_ERR_ARG, "more conds than extra adapters (n_extra_adapters)");
+        if (B <= 0 || (H & 7) || (W & 7)) return fail(FGDM_ERR_ARG, "latent size must be divisible by 8 for the adapter");
+        for (int kk = 0; kk < nc; ++kk) {
+            Tensor c4 = talloc(B, H, W, 4), f[4];
+            if (!c4.p) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (nchw_f32_to_nhwc_f16(conds[kk], c4.p, B, 4, H * W, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
+            CHK(adapter_run(n.xad_conv_in[kk], n.xad_body[kk], c4, f));
+            tfree(c4);
+            for (int i = 0; i < 4; ++i) {
+                Tensor& acc = n.xad_sum[i];
+                if (kk == 0) {
+                    acc = f[i];
+                    if (hipMalloc(&acc.p, acc.numel() * sizeof(half_t)) != hipSuccess) return fail(FGDM_ERR_NOMEM, "hipMalloc (adapter cache)");
+                    HIP_TRY(hipMemcpyAsync(acc.p, f[i].p, acc.numel() * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+                } else if (add_f16(acc.p, f[i].p, acc.p, acc.numel(), s) != FGDM_OK) {
+                    return fail(FGDM_ERR_HIP, "add kernel");
+                }
+                tfree(f[i]);
+            }
+        }
+        n.xad_valid = true;
         return FGDM_OK;
     }
 
@@ -1171,6 +1238,10 @@ struct fgdm_engine {
             CHK(block_fwd(n.input[i], i == 0 ? x4 : h, false, nullptr, ec, ctx16, nullptr, &nxt));
             if (use_adapter && (i + 1) % 3 == 0) {
                 if (k >= 4 || fa[k].numel() != nxt.numel()) return fail(FGDM_ERR_ARG, "adapter feature shape mismatch (latent size must be divisible by 8)");
+                if (n.xad_valid) {   // h = h + fk + fa[adapter_idx] (openaimodel.py:1301-1305): fk first, like the reference's sum order
+                    if (n.xad_sum[k].numel() != nxt.numel()) return fail(FGDM_ERR_ARG, "registered adapter conds do not match this batch / latent size");
+                    if (add_f16(nxt.p, n.xad_sum[k].p, nxt.p, nxt.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
+                }
                 if (add_f16(nxt.p, fa[k].p, nxt.p, nxt.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
                 tfree(fa[k]);
                 ++k;
@@ -1417,6 +1488,7 @@ void fgdm_destroy(fgdm_engine* e) {
     if (e->zero) (void)hipFree(e->zero);
     for (auto& n : e->cns) if (n.guided.p) (void)hipFree(n.guided.p);
     e->drop_context();
+    e->drop_adapter_conds();
     delete e;
 }
 
@@ -1478,6 +1550,7 @@ int fgdm_finalize_weights(fgdm_engine* e) {
     int rc = e->ensure_device();
     if (rc != FGDM_OK) return rc;
     e->drop_context();
+    e->drop_adapter_conds();
     rc = e->pack_net(e->unet);
     if (rc != FGDM_OK) return rc;
     for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }
@@ -1550,6 +1623,12 @@ int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const flo
     if (!e || !x || (!t && !t_float) || !eps_out) return FGDM_ERR_ARG;
     e->s = as_stream(stream);
     return e->apply_model(x, t, t_float, ctx, pcond, control_scales, B, H, W, flags, eps_out);
+}
+
+int fgdm_set_adapter_conds(fgdm_engine* e, const float* const* conds, int n_conds, int B, int H, int W, void* stream) {
+    if (!e) return FGDM_ERR_ARG;
+    e->s = as_stream(stream);
+    return e->set_adapter_conds(conds, n_conds, B, H, W);
 }
 
 int fgdm_set_context(fgdm_engine* e, const float* ctx, int B, void* stream) {

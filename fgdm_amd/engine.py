@@ -22,7 +22,8 @@ SD_CLIP = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hi
                num_attention_heads=12, max_position_embeddings=77)
 
 
-def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, workspace_bytes=0, vae=None, clip=None):
+def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, workspace_bytes=0, vae=None, clip=None,
+                num_prompts=1):
     """fgdm_config from the reference's UNetModel kwargs (models/config.yaml:33-48); `vae`: None (no first-stage
     decoder), True (SD_VAE) or the AutoencoderKL `ddconfig` dict; `clip`: None, True (SD_CLIP) or a CLIPTextConfig-style
     dict (text encoder in the engine)."""
@@ -46,6 +47,7 @@ def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, w
     c.n_controlnets = int(n_controlnets)
     c.hint_channels = hint_channels
     c.workspace_bytes = int(workspace_bytes)
+    c.n_extra_adapters = int(num_prompts) - 1      # AdaptUNetModel(num_prompts=...) (openaimodel.py:947,995-999)
     if vae:
         dd = dict(SD_VAE if vae is True else vae)
         if list(dd.get('attn_resolutions', ())):
@@ -97,11 +99,13 @@ def _ptr(t):
 class Engine:
     """One engine per device: owns packed weights + activation workspace in HBM."""
 
-    def __init__(self, cfg=None, use_adapter=False, n_controlnets=0, device=0, workspace_bytes=0, vae=None, clip=None):
+    def __init__(self, cfg=None, use_adapter=False, n_controlnets=0, device=0, workspace_bytes=0, vae=None, clip=None,
+                 num_prompts=1):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('fgdm_amd.Engine needs a GPU (MI355X); there is no CPU fallback')
-        self.config = make_config(cfg, use_adapter, n_controlnets, workspace_bytes=workspace_bytes, vae=vae, clip=clip)
+        self.config = make_config(cfg, use_adapter, n_controlnets, workspace_bytes=workspace_bytes, vae=vae, clip=clip,
+                                  num_prompts=num_prompts)
         self.has_vae = bool(vae)
         self.has_clip = bool(clip)
         self.device = torch.device('cuda', device)
@@ -115,6 +119,7 @@ class Engine:
         self.use_adapter = bool(use_adapter)
         self._hint_keys = [None] * n_controlnets
         self._ctx_obj, self._ctx_ver = None, -1     # context tensor whose K/V projections the engine holds
+        self._conds_key, self._conds_keep = None, None
         self.cache_context = os.environ.get('FGDM_CONTEXT_CACHE', '1') != '0'
 
     def close(self):
@@ -187,6 +192,23 @@ class Engine:
         self._check(self.lib.fgdm_set_hint(self.h, cn, _ptr(hint), B, Hh, Wh, _stream()), 'fgdm_set_hint')
         self._hint_keys[cn] = key
         self._hint_keep = hint
+
+    def set_adapter_conds(self, conds):
+        """AdaptUNetModel's `conds`: list of fp32 NCHW [B,4,H,W] latents (or None); their summed adapter features are
+        computed once and reused until a different list is given."""
+        if not conds:
+            if self._conds_key is not None:
+                self._check(self.lib.fgdm_set_adapter_conds(self.h, None, 0, 0, 0, 0, _stream()), 'fgdm_set_adapter_conds')
+                self._conds_key, self._conds_keep = None, None
+            return
+        key = tuple((id(c), c._version, tuple(c.shape)) for c in conds)
+        if key == self._conds_key:
+            return
+        dev = [c.to(self.device, torch.float32).contiguous() for c in conds]
+        B, _, H, W = dev[0].shape
+        ptrs = (C.c_void_p * len(dev))(*[c.data_ptr() for c in dev])
+        self._check(self.lib.fgdm_set_adapter_conds(self.h, ptrs, len(dev), B, H, W, _stream()), 'fgdm_set_adapter_conds')
+        self._conds_key, self._conds_keep = key, list(conds)
 
     def apply_model(self, x, t, ctx, control_scales=None, flags=0, pcond=None, out=None):
         x = x.to(self.device, torch.float32).contiguous()

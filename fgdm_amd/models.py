@@ -46,7 +46,7 @@ class DiffusionWrapper:
 
 
 class LatentDiffusion(_Buffers):
-    def __init__(self, unet_config=None, engine=None, use_adapter=True, n_controlnets=0, timesteps=1000,
+    def __init__(self, unet_config=None, engine=None, use_adapter=True, n_controlnets=0, num_prompts=1, timesteps=1000,
                  beta_schedule='linear', linear_start=0.00085, linear_end=0.012, cosine_s=8e-3, given_betas=None,
                  v_posterior=0.0, parameterization='eps', conditioning_key='crossattn', scale_factor=0.18215,
                  channels=4, image_size=32, log_every_t=200, clip_denoised=False, device=0, first_stage_config=None,
@@ -57,6 +57,7 @@ class LatentDiffusion(_Buffers):
             raise NotImplementedError("only conditioning_key='crossattn' is on the hot path (models/config.yaml:15)")
         self.engine = engine if engine is not None else _k.Engine(unet_config, use_adapter=use_adapter,
                                                                    n_controlnets=n_controlnets, device=device,
+                                                                   num_prompts=num_prompts,
                                                                    vae=self._ddconfig(first_stage_config),
                                                                    clip=self._clipconfig(cond_stage_config))
         self.device = self.engine.device
@@ -183,7 +184,12 @@ class LatentDiffusion(_Buffers):
         flags = _lib.FLAG_NO_CONTROL
         if kwargs.get('use_original', False):
             flags |= _lib.FLAG_USE_ORIGINAL
-        return self.engine.apply_model(x_noisy, t, self._context(cond), flags=flags, pcond=kwargs.get('pcond'))
+        # AdaptUNetModel.forward(x, t, context, control=None, conds=None) (openaimodel.py:1263): `control` replaces the
+        # adapter's prompt (UNetModel calls it `pcond`), `conds` feed the extra adapters
+        if 'conds' in kwargs or getattr(self.engine, '_conds_key', None) is not None:
+            self.engine.set_adapter_conds(kwargs.get('conds'))
+        pcond = kwargs.get('pcond', kwargs.get('control'))
+        return self.engine.apply_model(x_noisy, t, self._context(cond), flags=flags, pcond=pcond)
 
     # ---- closed-form pieces
     def _at(self, name, t):

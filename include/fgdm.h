@@ -45,7 +45,8 @@ typedef struct fgdm_config {
      * clip_layers = 0: engine without one.  openai/clip-vit-large-patch14: 12 layers, width 768, 12 heads, mlp 3072,
      * vocab 49408, 77 positions. */
     int32_t clip_layers, clip_width, clip_heads, clip_mlp, clip_vocab, clip_max_len;
-    int32_t reserved_;
+    int32_t n_extra_adapters;  /* AdaptUNetModel num_prompts - 1 (openaimodel.py:993-999): further Adapters whose features are
+                                * summed onto the FG-DM adapter's; needs use_adapter = 1 */
 } fgdm_config;
 
 #define FGDM_DTYPE_F32 0
@@ -84,6 +85,12 @@ int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int 
  * (openaimodel.py:838-841) fp32 NCHW or NULL (= x).  Timesteps: int64 `t`, or fractional fp32 `t_float` when non-NULL
  * (timestep_embedding accepts fractional t, util.py:165; DPM-Solver feeds (t_continuous - 1/N) * 1000).
  * ctx: fp32 [B,77,context_dim], or NULL to use the context registered with fgdm_set_context. */
+/* AdaptUNetModel.forward(..., conds=[...]) (openaimodel.py:1263-1320): n_conds <= n_extra_adapters condition latents,
+ * each fp32 NCHW [B,4,H,W] (device).  adapters[k](conds[k]) does not depend on x or t, so the summed features are
+ * computed here once and added in every later fgdm_apply_model of the same B, H, W (the reference's `control` prompt is
+ * fgdm_apply_model's `pcond`).  n_conds = 0 clears them (conds=None). */
+int fgdm_set_adapter_conds(fgdm_engine* e, const float* const* conds, int n_conds, int B, int H, int W, void* stream);
+
 /* The conditioning is loop-invariant (ddim.py:147-162 hands the same `cond` to every step): fgdm_set_context projects
  * ctx fp32 [B,77,context_dim] (device) through every cross-attention layer's to_k / to_v (attention.py:183-186) once;
  * fgdm_apply_model calls with ctx == NULL and the same B then reuse those projections.  A later fgdm_set_context or

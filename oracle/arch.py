@@ -163,8 +163,9 @@ def time_adapter_param_shapes(cin=4, channels=ADAPTER_CHANNELS, nums_rb=2, temb=
     return p
 
 
-def unet_param_shapes(cfg, adapter=True, prefix=''):
-    """State-dict keys -> shapes of the reference UNetModel (adapter: False | True (Adapter) | 'time' (TimeAdapter))."""
+def unet_param_shapes(cfg, adapter=True, prefix='', num_prompts=1):
+    """State-dict keys -> shapes of the reference UNetModel (adapter: False | True (Adapter) | 'time' (TimeAdapter));
+    num_prompts > 1: AdaptUNetModel (openaimodel.py:993-999) with `adapters.{k}` registered right after `adapter`."""
     mc = cfg['model_channels']
     temb = 4 * mc
     ctx = cfg['context_dim']
@@ -178,6 +179,8 @@ def unet_param_shapes(cfg, adapter=True, prefix=''):
         p.update(time_adapter_param_shapes(cfg['in_channels'], temb=temb, prefix=prefix + 'adapter.'))
     elif adapter:
         p.update(adapter_param_shapes(cfg['in_channels'], prefix=prefix + 'adapter.'))
+        for kk in range(num_prompts - 1):
+            p.update(adapter_param_shapes(cfg['in_channels'], prefix=f'{prefix}adapters.{kk}.'))
     for i, layers in enumerate(inp):
         _block_params(p, f'{prefix}input_blocks.{i}.', layers, temb, ctx)
     _block_params(p, f'{prefix}middle_block.', mid, temb, ctx)

@@ -159,13 +159,16 @@ def time_adapter_forward(p, pre, x, emb, cin=4):
 
 
 def unet_forward(p, cfg, x, t, ctx, prefix='', use_adapter=False, pcond=None,
-                 control=None, only_mid_control=False):
+                 control=None, only_mid_control=False, conds=None):
     """eps = UNet(x, t, ctx).
 
     use_adapter=False, control=None : UNetModel.forward_original (openaimodel.py:753-806)
     use_adapter=True                : UNetModel.forward with FG-DM adapter (openaimodel.py:808-884);
                                       feature k is added after input block 3k+2 *before* the skip push
     control=[13 tensors]            : ControlledUnetModel.forward (cldm.py:27-50); list is consumed from the end
+    conds=[tensors]                 : AdaptUNetModel.forward (openaimodel.py:1263-1320, num_prompts = len(conds) + 1):
+                                      `adapters.{k}(conds[k])` features are summed onto the `adapter(prompt)` features
+                                      (prompt = pcond, the reference's `control` argument, or x)
     """
     inp, mid, out = arch.unet_blocks(cfg)
     emb = time_embed(p, prefix, t, cfg['model_channels'])
@@ -175,6 +178,10 @@ def unet_forward(p, cfg, x, t, ctx, prefix='', use_adapter=False, pcond=None,
         fa = time_adapter_forward(p, prefix + 'adapter.', h if pcond is None else pcond, emb, cfg['in_channels'])
     elif use_adapter:
         fa = adapter_forward(p, prefix + 'adapter.', h if pcond is None else pcond, cfg['in_channels'])
+    if conds is not None:
+        for kdx, cond in enumerate(conds):
+            fk = adapter_forward(p, f'{prefix}adapters.{kdx}.', cond, cfg['in_channels'])
+            fa = [a + b for a, b in zip(fa, fk)]
     hs = []
     k = 0
     for i, layers in enumerate(inp):

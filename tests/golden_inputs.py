@@ -39,6 +39,9 @@ TABLE = {
     'sunet/x_T': ('sunet.xT', (2, 4, 16, 16)),
     'sunet/c': ('sunet.c', (2, 77, 768)),
     'sunet/uc': ('sunet.uc', (2, 77, 768)),
+    'adapt/cond0': ('adapt.cond0', (2, 4, 16, 16)),
+    'adapt/cond1': ('adapt.cond1', (2, 4, 16, 16)),
+    'adapt/control': ('adapt.control', (2, 4, 16, 16)),
     'vae/z8': ('vae.z8', (2, 4, 8, 8)),
     'vae/z16': ('vae.z16', (1, 4, 16, 16)),
 }

@@ -215,3 +215,27 @@ def test_context_cache_is_exact_and_invalidated(small_engine):
     # a context of another batch size replaces the cache
     d = e.apply_model(x[:1], t[:1], ctx[:1].contiguous(), flags=flags)
     assert torch.equal(d[0], c[0])
+
+
+def test_adapt_unet_multi_adapter_vs_reference_goldens():
+    """AdaptUNetModel (openaimodel.py:887-1320), num_prompts = 3: `conds` through two further adapters, `control` as the
+    adapter prompt; through the LatentDiffusion mirror's apply_model(..., conds=, control=) pass-through."""
+    from fgdm_amd import models
+    m = models.LatentDiffusion(gi.SD_CFG, use_adapter=True, num_prompts=3)
+    try:
+        sd = {k: synth.make_tensor(k, s) for k, s in m.engine.param_shapes().items()}
+        assert not m.load_state_dict(sd)[0]
+        g = gold('adapt_unet')
+        x, ctx = gi.get('unet/x16').cuda(), gi.get('unet/ctx').cuda()
+        t = torch.tensor([981, 1]).cuda()
+        conds = [gi.get('adapt/cond0').cuda(), gi.get('adapt/cond1').cuda()]
+        e = m.apply_model(x, t, ctx, conds=conds)
+        assert report('AdaptUNetModel conds vs reference golden', relerr(e.cpu(), g['eps_conds']), NET_TOL) < NET_TOL
+        e2 = m.apply_model(x, t, ctx, conds=conds)                      # cached adapter features
+        assert torch.equal(e, e2)
+        e = m.apply_model(x, t, ctx, conds=conds, control=gi.get('adapt/control').cuda())
+        assert report('AdaptUNetModel conds + control vs reference golden', relerr(e.cpu(), g['eps_conds_control']), NET_TOL) < NET_TOL
+        e = m.apply_model(x, t, ctx, conds=None)                        # conds=None: only the main adapter
+        assert report('AdaptUNetModel without conds vs reference golden', relerr(e.cpu(), g['eps_plain']), NET_TOL) < NET_TOL
+    finally:
+        m.engine.close()

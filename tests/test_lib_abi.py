@@ -50,6 +50,11 @@ def test_param_table_matches_reference_keys(lib):
     unet = _strip(got, 'model.diffusion_model.')
     assert list(unet.keys()) == list(ref['unet_time_adapter'].keys())
     assert all(tuple(ref['unet_time_adapter'][k]) == v for k, v in unet.items())
+    # AdaptUNetModel(num_prompts=3): two further adapters registered right after `adapter`
+    got = eng.param_shapes(eng.make_config(gi.SD_CFG, use_adapter=True, num_prompts=3))
+    unet = _strip(got, 'model.diffusion_model.')
+    assert list(unet.keys()) == list(ref['adapt_unet_3'].keys())
+    assert all(tuple(ref['adapt_unet_3'][k]) == v for k, v in unet.items())
     # plain SD UNet (= ControlledUnetModel keys)
     got = eng.param_shapes(eng.make_config(gi.SD_CFG))
     unet = _strip(got, 'model.diffusion_model.')
@@ -84,6 +89,8 @@ def test_unsupported_configs_are_rejected(lib):
         eng.make_config(gi.SD_CFG, vae=dict(eng.SD_VAE, attn_resolutions=[32]))
     with pytest.raises(ValueError):                     # decoder width must be a multiple of 64
         eng.param_shapes(eng.make_config(gi.SD_CFG, vae=dict(eng.SD_VAE, ch=96)))
+    with pytest.raises(ValueError):                     # extra adapters need the FG-DM adapter
+        eng.param_shapes(eng.make_config(gi.SD_CFG, use_adapter=False, num_prompts=2))
     with pytest.raises(ValueError):                     # text encoder: head dim must be 64
         eng.param_shapes(eng.make_config(gi.SD_CFG, clip=dict(eng.SD_CLIP, num_attention_heads=8)))
     with pytest.raises(ValueError):                     # adapter needs the SD-v1 topology

@@ -268,3 +268,22 @@ def test_ddim_over_reduced_unet():
                                       uc=gi.get('sunet/uc'), log_every_t=1)
     assert relerr(out, g['out']) < 1e-4
     assert relerr(torch.stack(inter['x_inter']), g['xinter']) < 1e-4
+
+
+def test_adapt_unet_multi_adapter():
+    """AdaptUNetModel (openaimodel.py:887-1320), num_prompts = 3: keys and the summed-adapter forward."""
+    ref = json.load(open(os.path.join(GOLD, 'param_keys.json')))['adapt_unet_3']
+    mine = arch.unet_param_shapes(gi.SD_CFG, adapter=True, num_prompts=3)
+    assert list(mine.keys()) == list(ref.keys())
+    assert all(tuple(ref[k]) == tuple(v) for k, v in mine.items())
+    g = gold('adapt_unet')
+    p = params(mine, 'model.diffusion_model.')
+    x, ctx = gi.get('unet/x16'), gi.get('unet/ctx')
+    t = torch.tensor([981, 1])
+    conds = [gi.get('adapt/cond0'), gi.get('adapt/cond1')]
+    kw = dict(prefix='model.diffusion_model.', use_adapter=True)
+    with torch.no_grad():
+        assert relerr(onn.unet_forward(p, gi.SD_CFG, x, t, ctx, conds=conds, **kw), g['eps_conds']) < 2e-5
+        assert relerr(onn.unet_forward(p, gi.SD_CFG, x, t, ctx, conds=conds, pcond=gi.get('adapt/control'), **kw),
+                      g['eps_conds_control']) < 2e-5
+        assert relerr(onn.unet_forward(p, gi.SD_CFG, x, t, ctx, **kw), g['eps_plain']) < 2e-5

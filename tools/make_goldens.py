@@ -154,6 +154,8 @@ def g_param_keys():
         out['unet_fgdm'] = sd(UNetModel(**ref_cfg(gi.SD_CFG)))
         out['unet_plain'] = sd(UNetModel(**ref_cfg(gi.SD_CFG, no_prompting=True)))
         out['unet_time_adapter'] = sd(UNetModel(**ref_cfg(gi.SD_CFG, use_time_adapter=True)))
+        from ldm.modules.diffusionmodules.openaimodel import AdaptUNetModel
+        out['adapt_unet_3'] = sd(AdaptUNetModel(**ref_cfg(gi.SD_CFG, num_prompts=3)))
         out['controlnet'] = sd(ControlNet(**ref_cfg(gi.SD_CFG, hint_channels=3)))
         out['controlled_unet'] = sd(ControlledUnetModel(**ref_cfg(gi.SD_CFG)))
         out['unet_small'] = sd(UNetModel(**ref_cfg(gi.SMALL_CFG, no_prompting=True)))
@@ -311,6 +313,23 @@ def g_unet_full():
         for hw in (8, 16):
             arrs[f'eps_tadapt{hw}'] = mt(gi.get(f'unet/x{hw}'), t, context=ctx)
     save('unet_full', **arrs)
+
+
+def g_adapt_unet():
+    """AdaptUNetModel (openaimodel.py:887-1320) with num_prompts = 3: two extra adapters over `conds`, `control` prompt."""
+    from ldm.modules.diffusionmodules.openaimodel import AdaptUNetModel
+    arrs = {}
+    with torch.no_grad():
+        m = AdaptUNetModel(**ref_cfg(gi.SD_CFG, num_prompts=3)).eval()
+        load_synth(m, 'model.diffusion_model.')
+        ctx = gi.get('unet/ctx')
+        t = torch.tensor([981, 1], dtype=torch.long)
+        x = gi.get('unet/x16')
+        conds = [gi.get('adapt/cond0'), gi.get('adapt/cond1')]
+        arrs['eps_conds'] = m(x, t, context=ctx, conds=conds)
+        arrs['eps_conds_control'] = m(x, t, context=ctx, conds=conds, control=gi.get('adapt/control'))
+        arrs['eps_plain'] = m(x, t, context=ctx)
+    save('adapt_unet', **arrs)
 
 
 def g_controlnet_full():
@@ -545,7 +564,7 @@ def g_sampler_unet():
 
 ALL = dict(schedule=g_schedule, ddpm_schedule=g_ddpm_schedule, param_keys=g_param_keys, ops=g_ops,
            unet_full=g_unet_full, controlnet_full=g_controlnet_full, small_nets=g_small_nets,
-           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip)
+           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip, adapt_unet=g_adapt_unet)
 
 
 def main():
