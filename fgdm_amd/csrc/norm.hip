@@ -38,7 +38,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
             float s[8], q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-            for (int p = p_begin + pi; p < p_end; p += PI) {
+            // four independent 16-byte loads in flight per thread (a dependent one-load loop leaves HBM idle)
+            int p = p_begin + pi;
+            for (; p + 3 * PI < p_end; p += 4 * PI) {
+                h8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + p + u * PI, o);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; s[e] += f; q[e] += f * f; }
+            }
+            for (; p < p_end; p += PI) {
                 const h8 v = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + p, o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
@@ -102,19 +113,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
     __syncthreads();
     const size_t total = (size_t)HW * P;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t p = i / P;
-        const int o = (int)(i - p * P);
-        const h8 v = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + p, o);
-        h8 r;
+    // four independent 16-byte loads in flight per thread
+    for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < total; i0 += (size_t)gridDim.x * 1024) {
+        h8 v[4];
+        size_t pix[4];
+        int oct[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = (o << 3) + e;
-            float f = (float)v[e] * scale[c] + shift[c];
-            if (silu) f = f / (1.0f + __expf(-f));
-            r[e] = (half_t)f;
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + (size_t)u * 256;
+            pix[u] = i / P;
+            oct[u] = (int)(i - pix[u] * P);
+            if (i < total) v[u] = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + pix[u], oct[u]);
         }
-        *(h8*)(out + ((size_t)b * HW + p) * C + (o << 3)) = r;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + (size_t)u * 256 >= total) break;
+            h8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = (oct[u] << 3) + e;
+                float f = (float)v[u][e] * scale[c] + shift[c];
+                if (silu) f = f / (1.0f + __expf(-f));
+                r[e] = (half_t)f;
+            }
+            *(h8*)(out + ((size_t)b * HW + pix[u]) * C + (oct[u] << 3)) = r;
+        }
     }
 }
 
@@ -135,7 +158,7 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
                        C1, HW, partial, ppc);
     const float inv_count = 1.0f / ((float)HW * (float)(C / 32));
     const size_t total = (size_t)HW * (C >> 3);
-    int gx = (int)((total + 255) / 256);
+    int gx = (int)((total + 1023) / 1024);
     // few, fat blocks: every block first reduces the sample's partial sums, so that prefix must be amortised
     // (measured on C3: 32 blocks per sample at B >= 8 is 6 % faster than 256)
     const int cap = 256 / (B < 8 ? B : 8);
