@@ -199,6 +199,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     //   all 14 fragment reads hoisted ahead of one 20-MFMA cluster with counted lgkmcnt waits (this version)  779 TF/s
     //   reads of the next half-stage issued under the MFMAs of the current one (barrier mid-stage)             685 TF/s
     //   wave groups 0-3 / 4-7 staggered by one barrier phase (2 barriers per stage)                           734 TF/s
+    //   SIMD-mate waves (w, w+4) refill at different points (after the barrier / after MFMA 10 of 20)          -3..-7 %
+    //   two K-steps per barrier (all DMAs of a stage pair must have landed at one wait)                         -8 %
     //     (the stagger lifts the no-global-load ablation from 1044 to 1187 TF/s but loses it again to the LDS-DMA
     //      fill path: 207 us compute-only, +46 us for the load instructions alone, +76 us for their memory traffic)
     auto wait_stage = [&](int k_needed) {     // stage k_needed landed; younger stages of this wave may stay in flight
