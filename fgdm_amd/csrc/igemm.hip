@@ -13,6 +13,7 @@
 // conflict-free for ds_read_b128 fragment reads; 2-stage LDS ring, one barrier per K-step; each wave
 // owns a (BM/WM)x(BN/WN) tile of v_mfma_f32_32x32x16_f16 accumulators; XCD-aware block->tile remap.
 #include "common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -298,6 +299,9 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
             force = 5;
         }
     }
+    // diagnostic knob for A/B runs (tools/ab_bench.sh): automatic choices take the 32x32x16 instantiations
+    static const bool mfma32 = getenv("FGDM_IGEMM_MFMA32") && atoi(getenv("FGDM_IGEMM_MFMA32")) != 0;
+    if (mfma32 && force >= 4 && force <= 6 && !a.force_cfg && !g_force_cfg) force += 3;
     if (force >= 4) return igemm2_launch(a, force - 4, s);
     struct Cfg { int bm, bn; float eff; int per_cu; };
     static const Cfg cfgs[] = {{128, 128, 1.00f, 2}, {128, 64, 0.80f, 3}, {64, 64, 0.62f, 4}};

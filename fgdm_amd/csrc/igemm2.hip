@@ -50,11 +50,21 @@ constexpr int ROWB = BK * 2;
 
 constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (more samples per tile: global loads)
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT>
+// MS = MFMA tile edge: 16 -> v_mfma_f32_16x16x32_f16 (one instruction per BK = 32 step and 16x16 tile), 32 ->
+// v_mfma_f32_32x32x16_f16 (two k-substeps per 32x32 tile).  Same flops, same LDS bytes, same accumulator registers; the
+// chip holds a higher clock under the 16x16x32 shape (this kernel is power-limited: all-zero operands run 1.3x faster
+// than random ones), measured +3..9 % on the conv shapes (tools/bench_igemm.py cfg 4 vs 7).
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS>
 __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, T = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
-    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int MI = TM / MS, NI = TN / MS;
+    constexpr int KS = MS == 32 ? 2 : 1;              // MFMA k-substeps per BK = 32 stage
+    constexpr int AR = MS == 32 ? 16 : 4;             // accumulator registers per tile
+    typedef float acc_t __attribute__((ext_vector_type(AR)));
+    // XOR swizzle of the four 16-byte chunks of a 64-byte LDS row, chosen per MFMA shape so that every 16-lane group
+    // of a ds_read_b128 fragment read covers all 64 banks (lane groups: MI355X_MICROARCH.md, LDS)
+    auto swz_of = [](int r) { return MS == 32 ? ((r >> 2) & 3) : (((r >> 3) & 1) << 1); };
     constexpr int A_INSTR = BM * 4 / 64, B_INSTR = BN * 4 / 64;     // wave-instructions (1 KiB each) per stage
     static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
     constexpr int LA = A_INSTR / NW, LB = (B_INSTR + NW - 1) / NW;  // A / B load slots per wave per stage
@@ -62,7 +72,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int A_BYTES = BM * ROWB;
     constexpr int RING_BYTES = STAGES * STAGE_BYTES;     // after the ring: bias[BN] then emb rows [RV_MAX][BN], fp32
-    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+    static_assert(TM % 32 == 0 && TN % MS == 0, "wave tile: 32-pixel epilogue passes, MFMA-sized channel tiles");
+    static_assert(!GEGLU || TN % 64 == 0, "GEGLU: whole 64-row [32 value | 32 gate] groups per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int q = (wave + i * NW) * 64 + lane, r = q >> 2, s = q & 3;
-        a_off[i] = (s ^ ((r >> 2) & 3)) << 3;                       // source-side swizzle (LDS image stays linear)
+        a_off[i] = (s ^ swz_of(r)) << 3;                            // source-side swizzle (LDS image stays linear)
         a_pix[i] = -1; a_yx[i] = 0;
         const int m = m0 + r;
         if (m < a.M) {
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         int idx = wave + i * NW;
         if (idx >= B_INSTR) idx = B_INSTR - 1;
         const int q = idx * 64 + lane, r = q >> 2, s = q & 3;
-        b_off[i] = (n0 + r) * a.K + ((s ^ ((r >> 2) & 3)) << 3);
+        b_off[i] = (n0 + r) * a.K + ((s ^ swz_of(r)) << 3);
         b_lds[i] = A_BYTES + idx * 1024;
     }
     const unsigned Hu = (unsigned)(a.H << up), Wu = (unsigned)(a.W << up);
@@ -150,18 +161,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     };
 
     // accumulators, TRANSPOSED: acc[nj][mi] = W-tile(nj) x X-tile(mi)^T ; row = channel, lane column = pixel
-    f32x16 acc[NI][MI];
+    acc_t acc[NI][MI];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+            for (int r = 0; r < AR; ++r) acc[j][i][r] = 0.f;
 
-    const int lrow = lane & 31, lh = lane >> 5, swz = (lrow >> 2) & 3;
-    int koff[2];
+    // fragment lane mapping: row of the MS-row tile, 16-byte k-chunk; lq = the lane's 4-channel block inside a tile
+    const int lrow = lane & (MS - 1), lh = lane / MS, swz = swz_of(lrow);
+    const int lq = 4 * lh;
+    int koff[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) koff[ks] = lrow * ROWB + (((ks * 2 + lh) ^ swz) << 4);
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = lrow * ROWB + ((((MS == 32 ? ks * 2 : 0) + lh) ^ swz) << 4);
 
     // ---- prologue: STAGES-1 stages in flight
     int tap = 0, cc = k_begin << 5;      // tap index, channel offset of the next stage to issue
@@ -219,35 +232,37 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         if (kt + STAGES - 1 < nk && !(a.debug & 1)) { stage(kt + STAGES - 1, tap, cc, (kt + STAGES - 1) % STAGES); advance(); }
         const char* As = smem + (kt % STAGES) * STAGE_BYTES + (wm * TM) * ROWB;
         const char* Bs = smem + (kt % STAGES) * STAGE_BYTES + A_BYTES + (wn * TN) * ROWB;
-        h8 xf[2][MI], wf[2][NI];
+        h8 xf[KS][MI], wf[KS][NI];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {     // read order = MFMA consumption order
+        for (int ks = 0; ks < KS; ++ks) {     // read order = MFMA consumption order
 #pragma unroll
-            for (int i = 0; i < MI; ++i) xf[ks][i] = *(const h8*)(As + i * 32 * ROWB + koff[ks]);
+            for (int i = 0; i < MI; ++i) xf[ks][i] = *(const h8*)(As + i * MS * ROWB + koff[ks]);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) wf[ks][j] = *(const h8*)(Bs + j * 32 * ROWB + koff[ks]);
+            for (int j = 0; j < NI; ++j) wf[ks][j] = *(const h8*)(Bs + j * MS * ROWB + koff[ks]);
         }
         __builtin_amdgcn_sched_barrier(0);     // keep all reads ahead of the MFMA cluster
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) {
+                    if constexpr (MS == 32) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
+                    else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
+                }
     }
 
     if constexpr (SPLIT) {  // split-K: raw fp32 partial tile -> ws[split][row][col]; igemm_splitk_reduce finishes the job
         float* wsp = a.ws + (size_t)split * a.M * a.N;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int row = m0 + wm * TM + i * 32 + lrow;
+            const int row = m0 + wm * TM + i * MS + lrow;
             if (row >= a.M) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = n0 + wn * TN + j * 32 + 8 * g + 4 * lh;
+                for (int g = 0; g < AR / 4; ++g) {
+                    const int col = n0 + wn * TN + j * MS + (MS == 32 ? 8 * g : 0) + lq;
                     f32x4 pk = {acc[j][i][g * 4], acc[j][i][g * 4 + 1], acc[j][i][g * 4 + 2], acc[j][i][g * 4 + 3]};
                     *(f32x4*)(wsp + (size_t)row * a.N + col) = pk;
                 }
@@ -259,12 +274,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) sink += acc[j][i][0] + acc[j][i][15];
+            for (int i = 0; i < MI; ++i) sink += acc[j][i][0] + acc[j][i][AR - 1];
         if (sink == 12345.678f) ((float*)a.out)[0] = sink;
         return;
     }
     // ---------------------------------------------------------------- epilogue
-    // acc[j][i][r]: channel = n0 + wn*TN + j*32 + (r&3) + 8*(r>>2) + 4*lh ; pixel = m0 + wm*TM + i*32 + lrow
+    // MS = 32: acc[j][i][r]: channel = n0 + wn*TN + j*32 + (r&3) + 8*(r>>2) + 4*lh ; pixel = m0 + wm*TM + i*32 + lrow
+    // MS = 16: acc[j][i][r]: channel = n0 + wn*TN + j*16 + 4*lh + r            ; pixel = m0 + wm*TM + i*16 + lrow
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // all waves are out of the K loop: the ring is free for staging
     constexpr int OUT_TN = GEGLU ? TN / 2 : TN;          // output channels this wave produces
@@ -277,18 +293,24 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     const int nvalid = GEGLU ? a.N / 2 : a.N;                            // valid output columns overall
     const float* bw = bias_l + wn * TN;                                  // this wave's slice of the staged bias
 
+    constexpr int PT = 32 / MS;                          // MFMA pixel tiles per 32-pixel staging pass
+    constexpr int NG = AR / 4;                           // 4-channel register quads per accumulator tile
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int row = m0 + wm * TM + i * 32 + lrow;     // this lane's pixel
+    for (int ip = 0; ip < TM / 32; ++ip) {
+#pragma unroll
+      for (int hf = 0; hf < PT; ++hf) {
+        const int i = ip * PT + hf;
+        const int prow = hf * MS + lrow;                  // this lane's pixel inside the 32-pixel pass
+        const int row = m0 + wm * TM + ip * 32 + prow;    // ... and in the whole problem
         const int bsmp = (a.rowvec && row < a.M) ? row / rps : smp0;
         const float* rw = rv_l + (bsmp - smp0) * BN + wn * TN;
         // ---- registers -> (bias, emb, activation, scale) -> fp16 -> LDS [pixel][channel]
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            if (GEGLU && (j & 1)) continue;
+            if (GEGLU && (MS == 32 ? (j & 1) : (j & 2))) continue;      // gate tiles are consumed with their value tile
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int wc = j * 32 + 8 * g + 4 * lh;                   // packed channel inside the wave tile
+            for (int g = 0; g < NG; ++g) {
+                const int wc = j * MS + (MS == 32 ? 8 * g : 0) + lq;      // packed channel inside the wave tile
                 const f32x4 bq = *(const f32x4*)(bw + wc);
                 float v[4];
 #pragma unroll
@@ -310,17 +332,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if constexpr (GEGLU) {
+                if constexpr (GEGLU) {      // packed rows: 64-row groups [32 value | 32 gate]
+                    constexpr int GJ = MS == 32 ? 1 : 2;                 // gate tile = value tile + GJ
                     const f32x4 gq = *(const f32x4*)(bw + wc + 32);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j | 1][i][g * 4 + e] + gq[e]);
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j + GJ][i][g * 4 + e] + gq[e]);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= a.scale;
-                const int oc = GEGLU ? (j >> 1) * 32 + 8 * g + 4 * lh : wc;   // output channel inside the wave tile
+                // output channel inside the wave tile (GEGLU: value channels only, 32 per 64-row group)
+                const int oc = !GEGLU ? wc : (MS == 32 ? (j >> 1) * 32 + 8 * g + lq : (j >> 2) * 32 + (j & 1) * 16 + lq);
                 if (a.out_kind == OUT_F16) {
                     h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *(h4*)(cst + lrow * PITCH + oc * 2) = pk;
+                    *(h4*)(cst + prow * PITCH + oc * 2) = pk;
                 } else if (row < a.M && ocol0 + oc < nvalid) {
                     // direct paths (rare outputs): lane = pixel, 4 consecutive channels
                     const int ch = ocol0 + oc;
@@ -339,6 +363,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 }
             }
         }
+      }
         if (a.out_kind == OUT_F16) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private tile: no barrier needed
             // ---- LDS -> (+ residual) -> 16-byte row-contiguous global stores; all loads first, then all stores
@@ -349,7 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
             for (int it = 0; it < WB_IT; ++it) {
                 const int c = lane + it * 64;
                 const int pr = c / CPR, ck = c - pr * CPR;
-                const int grow = m0 + wm * TM + i * 32 + pr;
+                const int grow = m0 + wm * TM + ip * 32 + pr;
                 const int gcol = ocol0 + ck * 8;
                 ok[it] = c < 32 * CPR && grow < a.M && gcol < nvalid;
                 goff[it] = (size_t)grow * a.ld_out + gcol;
@@ -376,14 +401,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     }   // !SPLIT
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false, int MS = 16>
 int launch2(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4;      // + staged bias and emb rows
     static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT>;
+    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -392,10 +417,10 @@ int launch2(const IgemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(ntm * ntn * (SPLIT ? a.splitk : 1)), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
-template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU>
+template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU, int MS = 16>
 int launch2m(const IgemmArgs& a, hipStream_t s) {
-    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, STAGES, false, GEGLU>(a, s)
-                               : launch2<BM, BN, WM, WN, STAGES, true, GEGLU>(a, s);
+    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS>(a, s)
+                               : launch2<BM, BN, WM, WN, STAGES, true, GEGLU, false, MS>(a, s);
 }
 
 // out[m][n] = ((sum_s ws[s][m][n]) + bias + emb -> act) * scale + resid, fixed summation order
@@ -442,10 +467,11 @@ int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
-// cfg: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320     (all: 8 waves, 4-stage ring)
+// cfg: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320     (all: 8 waves, 4-stage ring, 16x16x32 MFMA)
+//      3..5 = the same tiles on the 32x32x16 MFMA (kept for A/B measurements: tools/bench_igemm.py cfg 7..9)
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if ((a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return FGDM_ERR_ARG;
-    const int bn = cfg == 1 ? 256 : 320;
+    const int bn = (cfg == 1 || cfg == 4) ? 256 : 320;
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
     const bool g = a.act == ACT_GEGLU;
     if (g && bn != 256) return FGDM_ERR_ARG;
@@ -458,6 +484,9 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
                 return a.mode == IG_LINEAR ? launch2<128, 320, 4, 2, 4, false, false, true>(a, s)
                                            : launch2<128, 320, 4, 2, 4, true, false, true>(a, s);
             return launch2m<128, 320, 4, 2, 4, false>(a, s);
+        case 3: return launch2m<256, 320, 4, 2, 4, false, 32>(a, s);
+        case 4: return g ? launch2m<256, 256, 4, 2, 4, true, 32>(a, s) : launch2m<256, 256, 4, 2, 4, false, 32>(a, s);
+        case 5: return launch2m<128, 320, 4, 2, 4, false, 32>(a, s);
         default: return FGDM_ERR_ARG;
     }
 }

@@ -248,6 +248,8 @@ BIG_CASES = [
     (4, 1, 8, 8, 64, 0, 320, 1, 1, 0, 0, 'cfg4 K=64 (2 stages < ring depth)'),
     (6, 1, 8, 8, 32 * 2, 0, 320, 1, 1, 0, 0, 'cfg6 K=64'),
 ]
+# cfg 4..6 run the 16x16x32 MFMA; cfg 7..9 are the same tiles on the 32x32x16 MFMA (kept for A/B measurements)
+BIG_CASES = BIG_CASES + [(c[0] + 3,) + c[1:-1] + (c[-1].replace('cfg%d' % c[0], 'cfg%d(mfma32)' % (c[0] + 3)),) for c in BIG_CASES]
 
 
 @pytest.mark.parametrize('case', BIG_CASES, ids=[c[-1] for c in BIG_CASES])
@@ -273,7 +275,7 @@ def test_linear_pipelined_kernel(lib):
         a, g = y.chunk(2, dim=-1)
         out = torch.empty(M, N // 2, dtype=torch.half, device='cuda')
         wd, bd = w.cuda(), b.cuda()
-        for cfg in (5,):
+        for cfg in (5, 8):
             lib.fgdm_debug_force_igemm_cfg(cfg)
             out.zero_()
             assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
@@ -285,7 +287,7 @@ def test_linear_pipelined_kernel(lib):
         ref = F.linear(x, w2, b2)
         res = h16(rnd((M, N2), 74))
         resd = res.half().cuda()
-        for cfg in (4, 6):
+        for cfg in (4, 6, 7, 9):
             lib.fgdm_debug_force_igemm_cfg(cfg)
             out = torch.empty(M, N2, dtype=torch.half, device='cuda')
             assert lib.fgdm_op_linear(_p(xd), _p(w2d), _p(b2d), _p(resd), M, K, N2, 0, 0, 0, 0, _p(out), _st()) == 0

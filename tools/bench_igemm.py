@@ -35,7 +35,7 @@ SHAPES = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--cfgs', default='0,4,5,6,7,8')
+    ap.add_argument('--cfgs', default='0,4,5,6,7,8,9')
     a = ap.parse_args()
     lib = _lib.load()
     cfgs = [int(c) for c in a.cfgs.split(',')]
