@@ -85,6 +85,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The library binds to whichever libamdhip64 the process already holds.  PyTorch-ROCm ships its own copy of the HIP
+    # runtime: if this library were loaded first it would pull in the system copy, the process would then hold two
+    # runtimes, and the second one sees "no ROCm-capable device".  Let torch (device memory / streams plumbing of the
+    # Python host layer) load its runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} not found: build it with `python -m fgdm_amd.build` '
                            '(the HIP engine is mandatory, there is no CPU fallback)')

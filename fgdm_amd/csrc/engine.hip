@@ -1469,14 +1469,20 @@ static int make_desc(const fgdm_config* cfg, fgdm_engine** out) {
 
 extern "C" {
 
+static std::string g_create_err;   // why the last fgdm_create failed (there is no engine to ask): fgdm_last_error(NULL)
+
 int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
     if (!cfg || !out) return FGDM_ERR_ARG;
     fgdm_engine* e = nullptr;
     int rc = make_desc(cfg, &e);
-    if (rc != FGDM_OK) return rc;
+    if (rc != FGDM_OK) { g_create_err = "unsupported configuration"; return rc; }
     e->device = device;
     rc = e->ensure_device();
-    if (rc != FGDM_OK) { delete e; return rc; }
+    if (rc != FGDM_OK) {
+        g_create_err = e->err + " [" + hipGetErrorString(hipGetLastError()) + "]";
+        delete e;
+        return rc;
+    }
     *out = e;
     return FGDM_OK;
 }
@@ -1492,7 +1498,7 @@ void fgdm_destroy(fgdm_engine* e) {
     delete e;
 }
 
-const char* fgdm_last_error(const fgdm_engine* e) { return e ? e->err.c_str() : "null engine"; }
+const char* fgdm_last_error(const fgdm_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 
 static fgdm_engine* g_desc = nullptr;
 static fgdm_config g_desc_cfg;

@@ -113,7 +113,8 @@ class Engine:
         h = C.c_void_p()
         rc = self.lib.fgdm_create(C.byref(self.config), device, C.byref(h))
         if rc != 0:
-            raise RuntimeError(f'fgdm_create failed: {rc}')
+            why = self.lib.fgdm_last_error(None)
+            raise RuntimeError(f'fgdm_create failed ({rc}): {why.decode() if why else ""}')
         self.h = h
         self.n_controlnets = n_controlnets
         self.use_adapter = bool(use_adapter)

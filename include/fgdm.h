@@ -59,7 +59,7 @@ typedef struct fgdm_config {
 
 int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out);
 void fgdm_destroy(fgdm_engine* e);
-const char* fgdm_last_error(const fgdm_engine* e);
+const char* fgdm_last_error(const fgdm_engine* e);   /* e == NULL: why the last fgdm_create failed */
 
 /* Parameter table: the reference state_dict keys the engine expects.  UNet keys carry the prefix
  * "model.diffusion_model." (adapter: "model.diffusion_model.adapter."), ControlNet k uses "control_model."
