@@ -35,12 +35,13 @@ def log(msg):
     print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
 
-def build_model(rank, world):
+def build_model(rank, world, first_stage=True):
     """ControlLDM mirror (reference API) over the HIP engine; frozen weights are generated on rank 0 only and
     shipped with ONE RCCL broadcast of a flat fp32 buffer (fgdm_amd/dist.py)."""
     from fgdm_amd import dist as fd, models, synth
     t0 = time.time()
-    model = models.ControlLDM(None, n_controlnets=1, device=torch.cuda.current_device(), first_stage_config=True)
+    model = models.ControlLDM(None, n_controlnets=1, device=torch.cuda.current_device(),
+                              first_stage_config=True if first_stage else None)
     shapes = model.engine.param_shapes()
     sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, 'cuda')
     missing, _ = model.load_state_dict(sd, strict=True)
@@ -97,6 +98,8 @@ def main():
     ap.add_argument('--prompts', type=int, default=PROMPTS_PER_GPU, help='prompts per GPU')
     ap.add_argument('--ddim-steps', type=int, default=DDIM_STEPS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-first-stage', action='store_true',
+                    help='skip the VAE decode that follows the timed region (PMC passes: counters then cover the path only)')
     ap.add_argument('--profile-stride', type=int, default=7,
                     help='HIP-event bracket every n-th kernel launch of the timed region (coprime with the 830 launches per '
                          'evaluation, so every layer shape is sampled uniformly); 1 = every launch')
@@ -115,7 +118,7 @@ def main():
 
     from fgdm_amd import synth
     from fgdm_amd import samplers
-    model, n_params, load_s = build_model(rank, world)
+    model, n_params, load_s = build_model(rank, world, first_stage=not a.no_first_stage)
     engine = model.engine
     sampler = samplers.ControlDDIMSampler(model)       # drop-in for controlnet/cldm/ddim_hacked.py:DDIMSampler
 
@@ -161,13 +164,15 @@ def main():
     assert torch.isfinite(out).all(), 'non-finite latents'
     # outside the timed region (VAE decode excluded from the metric, reported separately):
     # decode_first_stage of this rank's latents to 512x512 images
-    img = model.decode_first_stage(out)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    img = model.decode_first_stage(out)
-    torch.cuda.synchronize()
-    dec_s = time.perf_counter() - t1
-    assert tuple(img.shape) == (npg, 3, 8 * LATENT, 8 * LATENT) and torch.isfinite(img).all()
+    dec_s = None
+    if not a.no_first_stage:
+        img = model.decode_first_stage(out)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        img = model.decode_first_stage(out)
+        torch.cuda.synchronize()
+        dec_s = time.perf_counter() - t1
+        assert tuple(img.shape) == (npg, 3, 8 * LATENT, 8 * LATENT) and torch.isfinite(img).all()
 
     if rank == 0:
         # HBM traffic per launch of the dominant kernel family: measured offline with rocprofv3 PMC passes
@@ -207,10 +212,10 @@ def main():
             'attention_tflops': (prof['attention']['work'] / (prof['attention']['ms'] * 1e-3) / 1e12
                                  if prof['attention']['ms'] > 0 else 0.0),
             'norm_GBps': (prof['norm']['work'] / (prof['norm']['ms'] * 1e-3) / 1e9 if prof['norm']['ms'] > 0 else 0.0),
-            'first_stage_decode': {'ms_per_image': dec_s / npg * 1e3,
-                                   'images_per_s_including_decode': N / (dt / a.steps + dec_s),
-                                   'note': 'AutoencoderKL.decode of the sampled latents in the same engine, outside the '
-                                           'timed region; 1.27 TFLOP/image'},
+            'first_stage_decode': None if dec_s is None else {
+                'ms_per_image': dec_s / npg * 1e3, 'images_per_s_including_decode': N / (dt / a.steps + dec_s),
+                'note': 'AutoencoderKL.decode of the sampled latents in the same engine, outside the timed region; '
+                        '1.27 TFLOP/image'},
             'weights': {'params': n_params, 'load_s': round(load_s, 2)},
             'workspace': engine.workspace_stats(),
         }
