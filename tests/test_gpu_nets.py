@@ -239,3 +239,25 @@ def test_adapt_unet_multi_adapter_vs_reference_goldens():
         assert report('AdaptUNetModel without conds vs reference golden', relerr(e.cpu(), g['eps_plain']), NET_TOL) < NET_TOL
     finally:
         m.engine.close()
+
+
+def test_non_square_latent_and_batch_one_vs_oracle(small_engine):
+    """Latents need not be square (the scripts take --H / --W): 16x24 latent, hint 128x192, batch 1, against the oracle."""
+    from oracle import arch, nn as onn
+    cfg = gi.SMALL_CFG
+    x = torch.from_numpy(synth.latents(1, 16, 24, seed=31))
+    ctx = torch.from_numpy(synth.context(1, seed=32))
+    hint = torch.from_numpy(synth.hint(1, res=128, seed=33))
+    hint = torch.cat([hint, hint.flip(-1)[..., :64]], dim=-1).contiguous()          # 128 x 192
+    t = torch.tensor([501])
+    small_engine.set_hint(0, hint.cuda())
+    got = small_engine.apply_model(x, t, ctx, control_scales=gi.CTRL_SCALES)
+    p = {}
+    for pre, name, shapes in (('model.diffusion_model.', 'small.', arch.unet_param_shapes(cfg, adapter=False)),
+                              ('control_model.', 'small_cn.', arch.controlnet_param_shapes(cfg))):
+        for k, s in shapes.items():
+            p[pre + k] = torch.from_numpy(synth.make_tensor(name + k, s))
+    with torch.no_grad():
+        want = onn.control_ldm_apply(p, cfg, x, t, ctx, [hint], scales=gi.CTRL_SCALES)
+    assert tuple(got.shape) == (1, 4, 16, 24)
+    assert report('non-square 16x24 latent, batch 1, UNet+ControlNet vs oracle', relerr(got.cpu(), want), NET_TOL) < NET_TOL
