@@ -1735,12 +1735,12 @@ int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* u
     } else {
         HIP_TRY(hipMemcpyAsync(c2, cond, nctx * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    int rc = FGDM_OK;
+    int rc = e->set_context(c2, Bm);   // the conditioning is loop-invariant: project it once, pass ctx = NULL below
     for (int i = 0; i < S && rc == FGDM_OK; ++i) {
         const int index = S - 1 - i;   // reversed walk (ddim.py:137,148)
         HIP_TRY(hipMemcpyAsync(x2, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (cfg_on) HIP_TRY(hipMemcpyAsync(x2 + n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        rc = e->apply_model(x2, tdev + (size_t)index * Bm, nullptr, c2, nullptr, control_scales, Bm, H, W, flags, eps);
+        rc = e->apply_model(x2, tdev + (size_t)index * Bm, nullptr, nullptr, nullptr, control_scales, Bm, H, W, flags, eps);
         if (rc != FGDM_OK) break;
         rc = ddim_step(x, cfg_on ? eps + n : eps, cfg_on ? eps : nullptr, cfg_scale, alphas[index], alphas_prev[index], 0.f,
                        sqrt_one_minus_alphas[index], nullptr, x, nullptr, nullptr, n, s);

@@ -335,6 +335,7 @@ class Engine:
             sc_ptr = C.c_void_p(0)
         rc = self.lib.fgdm_sample_ddim(self.h, _ptr(x), _ptr(cond), _ptr(uncond), float(cfg_scale), S, ts, fa(alphas),
                                        fa(alphas_prev), fa(sqrt_one_minus_alphas), sc_ptr, B, H, W, flags, _stream())
+        self._ctx_obj, self._ctx_ver = None, -1      # the device-side loop registered its own context
         self._check(rc, 'fgdm_sample_ddim')
         return x
 

@@ -12,7 +12,7 @@ from fgdm_amd import build
 CSRC = os.path.join(os.path.dirname(os.path.abspath(build.__file__)), 'csrc')
 
 
-@pytest.mark.parametrize('src', ['igemm.hip', 'igemm2.hip', 'attention.hip', 'norm.hip', 'elementwise.hip', 'boundary.hip'])
+@pytest.mark.parametrize('src', ['igemm.hip', 'igemm2.hip', 'attention.hip', 'norm.hip', 'elementwise.hip', 'boundary.hip', 'text.hip'])
 def test_no_scratch(src, tmp_path):
     cmd = [build._hipcc(), *build.FLAGS, '-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, src),
            '-o', str(tmp_path / 'x.o')]
