@@ -1555,8 +1555,9 @@ int fgdm_finalize_weights(fgdm_engine* e) {
     if (!e) return FGDM_ERR_ARG;
     int rc = e->ensure_device();
     if (rc != FGDM_OK) return rc;
-    e->drop_context();
+    e->drop_context();          // everything derived from the previous weights is stale
     e->drop_adapter_conds();
+    for (auto& n : e->cns) if (n.guided.p) { (void)hipFree(n.guided.p); n.guided = Tensor{}; }
     rc = e->pack_net(e->unet);
     if (rc != FGDM_OK) return rc;
     for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }

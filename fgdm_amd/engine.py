@@ -181,18 +181,20 @@ class Engine:
     def finalize(self):
         self._check(self.lib.fgdm_finalize_weights(self.h), 'fgdm_finalize_weights')
         self._ctx_obj, self._ctx_ver = None, -1
+        self._hint_keys = [None] * self.n_controlnets
+        self._conds_key, self._conds_keep = None, None
 
     # ------------------------------------------------------------------ forward
     def set_hint(self, cn, hint):
-        """hint fp32 NCHW [B,3,8H,8W] in [0,1]; cached until a different tensor is given."""
-        key = (hint.data_ptr(), hint._version, tuple(hint.shape))
-        if self._hint_keys[cn] == key:
+        """hint fp32 NCHW [B,3,8H,8W] in [0,1]; cached until a different tensor is given.  The source object is kept
+        alive with the key, so its address and version counter cannot be recycled by another tensor."""
+        key = (id(hint), hint.data_ptr(), hint._version, tuple(hint.shape))
+        if self._hint_keys[cn] is not None and self._hint_keys[cn][0] == key:
             return
-        hint = hint.to(self.device, torch.float32).contiguous()
-        B, _, Hh, Wh = hint.shape
-        self._check(self.lib.fgdm_set_hint(self.h, cn, _ptr(hint), B, Hh, Wh, _stream()), 'fgdm_set_hint')
-        self._hint_keys[cn] = key
-        self._hint_keep = hint
+        dev = hint.to(self.device, torch.float32).contiguous()
+        B, _, Hh, Wh = dev.shape
+        self._check(self.lib.fgdm_set_hint(self.h, cn, _ptr(dev), B, Hh, Wh, _stream()), 'fgdm_set_hint')
+        self._hint_keys[cn] = (key, hint)
 
     def set_adapter_conds(self, conds):
         """AdaptUNetModel's `conds`: list of fp32 NCHW [B,4,H,W] latents (or None); their summed adapter features are
