@@ -19,6 +19,11 @@
 //   * d = 40 (padded to 48 in the contraction) has spare k slots: Q is pre-multiplied by log2(e) d^-1/2 and slot 40
 //     carries K = 1, Q = -m (the running max, kept fp16-representable), so the MFMA itself delivers
 //     s log2(e) d^-1/2 - m and the per-score work shrinks to max3 + exp2 + pack (FOLD).
+//
+// Measured and rejected (MI355X, C3): software-pipelining the loop inside a wave (QK^T of tile k+1 issued before the
+// softmax of tile k, ping-pong score registers, K / V buffers out of phase, still one barrier per tile) needs 194 VGPRs
+// at d = 40 -> 2 waves per SIMD instead of 3 -> 505 TF/s against 600; forced to 168 VGPRs it spills -> 436 TF/s.  The
+// overlap of MFMA and VALU phases comes from the three resident waves here.
 #include "common.h"
 
 #define ATT_THR 8.0f
