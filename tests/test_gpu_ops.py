@@ -305,3 +305,24 @@ def test_linear_pipelined_kernel(lib):
                 assert relerr(outT[:, :, :rps].float().cpu(), want) < TOL, (cfg, rps)
     finally:
         lib.fgdm_debug_force_igemm_cfg(0)
+
+
+@pytest.mark.parametrize('gain,shift', [(6.0, 0.0), (3.0, 2.0), (0.05, 0.0)], ids=['large logits', 'all-negative rows', 'flat rows'])
+def test_attention_logit_ranges_d40(lib, gain, shift):
+    """d = 40 keeps the softmax scale and the running max inside the QK^T MFMA (fp16 Q pad slot): logits spanning
+    hundreds of log2 units, rows whose logits are all strongly negative (first tile must still set the offset) and
+    almost flat rows must all stay within the per-kernel tolerance."""
+    B, Hh, T, Tk, d = 1, 2, 256, 320, 40
+    Cc = Hh * d
+    q, k, v = h16(rnd((B, T, Cc), 71) * gain), h16(rnd((B, Tk, Cc), 72) * gain), h16(rnd((B, Tk, Cc), 73))
+    if shift:
+        q, k = h16(q.abs() + shift), h16(-(k.abs() + shift))        # every q.k strongly negative
+    split = lambda t: t.view(B, -1, Hh, d).permute(0, 2, 1, 3)
+    sim = torch.matmul(split(q).double(), split(k).double().transpose(-1, -2)) * d ** -0.5
+    ref = torch.matmul(sim.softmax(-1), split(v).double()).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    vt = v.permute(0, 2, 1).half().contiguous()
+    out = torch.empty(B, T, Cc, dtype=torch.half, device='cuda')
+    qd, kd, vtd = q.half().cuda(), k.half().cuda(), vt.cuda()
+    assert lib.fgdm_op_attention(_p(qd), Cc, _p(kd), Cc, _p(vtd), Tk, _p(out), Cc, B, Hh, T, Tk, d, _st()) == 0
+    assert torch.isfinite(out).all()
+    assert relerr(out.float().cpu(), ref) < 2 * TOL, float(sim.abs().max())
