@@ -214,6 +214,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     //   wave groups 0-3 / 4-7 staggered by one barrier phase (2 barriers per stage)                           734 TF/s
     //   SIMD-mate waves (w, w+4) refill at different points (after the barrier / after MFMA 10 of 20)          -3..-7 %
     //   two K-steps per barrier (all DMAs of a stage pair must have landed at one wait)                         -8 %
+    //   full stagger, re-measured on the 16x16x32 kernel incl. all-zero operands (no power limit) and on the
+    //     half-empty grids of the 16x16 level: SIMD-mates half a K-step apart, one mate refills + reads fragments
+    //     while the other runs its 40 MFMAs, 2 barriers per step: -10 % (256x320), -15..-25 % (128x320): the
+    //     refill + fragment-read phase is LONGER than the MFMA phase, so pairing them does not hide it
     //     (the stagger lifts the no-global-load ablation from 1044 to 1187 TF/s but loses it again to the LDS-DMA
     //      fill path: 207 us compute-only, +46 us for the load instructions alone, +76 us for their memory traffic)
     auto wait_stage = [&](int k_needed) {     // stage k_needed landed; younger stages of this wave may stay in flight
