@@ -261,3 +261,34 @@ def test_non_square_latent_and_batch_one_vs_oracle(small_engine):
         want = onn.control_ldm_apply(p, cfg, x, t, ctx, [hint], scales=gi.CTRL_SCALES)
     assert tuple(got.shape) == (1, 4, 16, 24)
     assert report('non-square 16x24 latent, batch 1, UNet+ControlNet vs oracle', relerr(got.cpu(), want), NET_TOL) < NET_TOL
+
+
+def test_two_controlnets_sum_of_residuals_vs_oracle():
+    """BASELINE configs 4/5: several ControlNets on one UNet.  Not in the reference (one control_model per ControlLDM);
+    defined as the element-wise sum of the scaled 13-tensor residual lists, each encoder pinned separately by
+    the ControlNet goldens.  Through the ControlLDM mirror with one hint per control model."""
+    from fgdm_amd import models
+    from oracle import nn as onn
+    cfg = gi.SMALL_CFG
+    m = models.ControlLDM(cfg, n_controlnets=2)
+    try:
+        sd = {k: synth.make_tensor(k, s) for k, s in m.engine.param_shapes().items()}
+        assert any(k.startswith('control_model_1.') for k in sd)
+        assert not m.load_state_dict(sd)[0]
+        m.control_scales = [0.7] * 13
+        B, H = 2, 16
+        x = torch.from_numpy(synth.latents(B, H, H, seed=41))
+        ctx = torch.from_numpy(synth.context(B, seed=42))
+        h0 = torch.from_numpy(synth.hint(B, res=8 * H, seed=43))
+        h1 = torch.from_numpy(synth.hint(B, res=8 * H, seed=44))
+        t = torch.tensor([741, 21])
+        got = m.apply_model(x.cuda(), t.cuda(), {'c_concat': [h0.cuda(), h1.cuda()], 'c_crossattn': [ctx.cuda()]})
+        p = {k: torch.from_numpy(v) for k, v in sd.items()}
+        with torch.no_grad():
+            want = onn.control_ldm_apply(p, cfg, x, t, ctx, [h0, h1], scales=[0.7] * 13,
+                                         cn_prefixes=('control_model.', 'control_model_1.'))
+            one = onn.control_ldm_apply(p, cfg, x, t, ctx, [h0], scales=[0.7] * 13)
+        assert report('two ControlNets (summed residuals) vs oracle', relerr(got.cpu(), want), NET_TOL) < NET_TOL
+        assert relerr(want, one) > 1e-2          # the second control model really contributes
+    finally:
+        m.engine.close()
