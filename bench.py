@@ -35,12 +35,12 @@ def log(msg):
     print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
 
-def build_model(rank, world, first_stage=True):
+def build_model(rank, world, first_stage=True, n_controlnets=1):
     """ControlLDM mirror (reference API) over the HIP engine; frozen weights are generated on rank 0 only and
     shipped with ONE RCCL broadcast of a flat fp32 buffer (fgdm_amd/dist.py)."""
     from fgdm_amd import dist as fd, models, synth
     t0 = time.time()
-    model = models.ControlLDM(None, n_controlnets=1, device=torch.cuda.current_device(),
+    model = models.ControlLDM(None, n_controlnets=n_controlnets, device=torch.cuda.current_device(),
                               first_stage_config=True if first_stage else None)
     shapes = model.engine.param_shapes()
     sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, 'cuda')
@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--prompts', type=int, default=PROMPTS_PER_GPU, help='prompts per GPU')
     ap.add_argument('--ddim-steps', type=int, default=DDIM_STEPS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--controlnets', type=int, default=1,
+                    help='control models per UNet (1 = the metric\'s config C3; 2 / 3 = BASELINE configs C4 / C5, use --prompts 8)')
     ap.add_argument('--no-first-stage', action='store_true',
                     help='skip the VAE decode that follows the timed region (PMC passes: counters then cover the path only)')
     ap.add_argument('--profile-stride', type=int, default=7,
@@ -118,7 +120,7 @@ def main():
 
     from fgdm_amd import synth
     from fgdm_amd import samplers
-    model, n_params, load_s = build_model(rank, world, first_stage=not a.no_first_stage)
+    model, n_params, load_s = build_model(rank, world, first_stage=not a.no_first_stage, n_controlnets=a.controlnets)
     engine = model.engine
     sampler = samplers.ControlDDIMSampler(model)       # drop-in for controlnet/cldm/ddim_hacked.py:DDIMSampler
 
@@ -128,10 +130,10 @@ def main():
     x_T = torch.from_numpy(synth.latents(N, LATENT, LATENT, seed=42)[sl]).cuda()
     cond = torch.from_numpy(synth.context(N, seed=43)[sl]).cuda()
     uncond = torch.from_numpy(synth.context(N, seed=44)[sl]).cuda()
-    hint = torch.from_numpy(synth.hint(N, 512, seed=45)[sl]).cuda()
+    hints = [torch.from_numpy(synth.hint(N, 512, seed=45 + k)[sl]).cuda() for k in range(a.controlnets)]
     # the call the reference makes at controlnet/initialize_cn.py:86-96 (guess_mode=False: control on both branches)
-    c_cond = {'c_concat': [hint], 'c_crossattn': [cond]}
-    c_uncond = {'c_concat': [hint], 'c_crossattn': [uncond]}
+    c_cond = {'c_concat': hints, 'c_crossattn': [cond]}
+    c_uncond = {'c_concat': hints, 'c_crossattn': [uncond]}
 
     def one_step():
         out, _ = sampler.sample(a.ddim_steps, npg, (4, LATENT, LATENT), c_cond, verbose=False, eta=0.0, x_T=x_T,
@@ -185,6 +187,8 @@ def main():
             pass
         images = N * a.steps
         value = images / dt
+        # 2*50*(803.27 + k*268.57) + k*14.72 GFLOP per image
+        tflop_per_image = TFLOP_PER_IMAGE if a.controlnets == 1 else (100 * (803.27 + a.controlnets * 268.57) + a.controlnets * 14.72) / 1e3
         ig = prof['igemm']
         achieved = ig['work'] / (ig['ms'] * 1e-3) / 1e12 if ig['ms'] > 0 else 0.0
         res = {
@@ -192,7 +196,9 @@ def main():
             'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2] (C3): SD-v1.5 UNet + seg-ControlNet, hint 512x512, '
+            'config': {'workload': ('BASELINE configs[2] (C3): SD-v1.5 UNet + seg-ControlNet, hint 512x512, ' if a.controlnets == 1 else
+                                    f'NOT the metric\'s config: SD-v1.5 UNet + {a.controlnets} ControlNets (summed residuals), hints 512x512, ')
+                                   +
                                    f'{npg} prompts per GPU, {a.ddim_steps} DDIM steps eta=0, CFG {CFG_SCALE} '
                                    'as one 2B batch, latent 4x64x64, through the drop-in ControlLDM.apply_model + '
                                    'DDIMSampler.sample API; synthetic weights/latents/contexts/hints',
@@ -207,8 +213,8 @@ def main():
                          'avg_launch_us': ig['ms'] * 1e3 / max(ig['launches'], 1),
                          'algorithmic_tflop_per_launch': ig['work'] / max(ig['launches'], 1) / 1e12},
             'kernel_time_ms_est': {k: round(v['ms'] * a.profile_stride, 3) for k, v in prof.items()},
-            'whole_path_tflops': value * TFLOP_PER_IMAGE * (a.ddim_steps / DDIM_STEPS),
-            'whole_path_mfma_frac': value * TFLOP_PER_IMAGE * (a.ddim_steps / DDIM_STEPS) / (PEAK_TFLOPS * world),
+            'whole_path_tflops': value * tflop_per_image * (a.ddim_steps / DDIM_STEPS),
+            'whole_path_mfma_frac': value * tflop_per_image * (a.ddim_steps / DDIM_STEPS) / (PEAK_TFLOPS * world),
             'attention_tflops': (prof['attention']['work'] / (prof['attention']['ms'] * 1e-3) / 1e12
                                  if prof['attention']['ms'] > 0 else 0.0),
             'norm_GBps': (prof['norm']['work'] / (prof['norm']['ms'] * 1e-3) / 1e9 if prof['norm']['ms'] > 0 else 0.0),
