@@ -106,3 +106,30 @@ def test_dpm_solver_and_encode_on_device():
     smp.make_schedule(20, ddim_eta=0.0, verbose=False)
     enc, _ = smp.encode(gi.get('samp/x0').cuda(), c, 12, unconditional_guidance_scale=5.0, unconditional_conditioning=uc)
     assert report('DDIM encode (inversion) 12 steps vs reference', relerr(enc.cpu(), g['encode_cfg']), STOL) < STOL
+
+
+def test_sampling_is_bitwise_reproducible():
+    """No atomics anywhere on the path: the same sample() call twice gives identical latents, also after other work
+    (a different batch size) ran in between and with the context cache cold or warm."""
+    cfg = gi.SMALL_CFG
+    model = models.ControlLDM(cfg, n_controlnets=1)
+    try:
+        sd = {k: synth.make_tensor(k, s) for k, s in model.engine.param_shapes().items()}
+        assert not model.load_state_dict(sd)[0]
+        B, H = 2, 16
+        x_T = torch.from_numpy(synth.latents(B, H, H, seed=51)).cuda()
+        c, uc = torch.from_numpy(synth.context(B, seed=52)).cuda(), torch.from_numpy(synth.context(B, seed=53)).cuda()
+        hint = torch.from_numpy(synth.hint(B, 8 * H, seed=54)).cuda()
+        cond = {'c_concat': [hint], 'c_crossattn': [c]}
+        ucond = {'c_concat': [hint], 'c_crossattn': [uc]}
+
+        def run(xT, cd, ucd, n):
+            return samplers.ControlDDIMSampler(model).sample(5 if n else 4, xT.shape[0], (4, H, H), cd, verbose=False, eta=0.0,
+                                                             x_T=xT, unconditional_guidance_scale=9.0,
+                                                             unconditional_conditioning=ucd)[0].clone()
+        a = run(x_T, cond, ucond, 0)
+        run(x_T[:1], {'c_concat': [hint[:1]], 'c_crossattn': [c[:1]]}, {'c_concat': [hint[:1]], 'c_crossattn': [uc[:1]]}, 1)
+        b = run(x_T, cond, ucond, 0)
+        assert torch.equal(a, b)
+    finally:
+        model.engine.close()
