@@ -23,7 +23,9 @@
 // Measured and rejected (MI355X, C3): software-pipelining the loop inside a wave (QK^T of tile k+1 issued before the
 // softmax of tile k, ping-pong score registers, K / V buffers out of phase, still one barrier per tile) needs 194 VGPRs
 // at d = 40 -> 2 waves per SIMD instead of 3 -> 505 TF/s against 600; forced to 168 VGPRs it spills -> 436 TF/s.  The
-// overlap of MFMA and VALU phases comes from the three resident waves here.
+// overlap of MFMA and VALU phases comes from the three resident waves here.  One 32-key sub-tile at a time (16 live
+// score registers, 128 VGPRs, 4 waves per SIMD, no spill) is not faster either (549 vs 557-606 TF/s): v_exp_f32 issues
+// at a quarter of the VALU rate, the 33 exp2 per 64 keys are ~530 of the ~1000 cycles a wave-tile takes on its SIMD.
 #include "common.h"
 
 #define ATT_THR 8.0f
