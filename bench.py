@@ -212,6 +212,10 @@ def main():
                          'timed_launches': ig['launches'], 'launch_sampling_stride': a.profile_stride,
                          'avg_launch_us': ig['ms'] * 1e3 / max(ig['launches'], 1),
                          'algorithmic_tflop_per_launch': ig['work'] / max(ig['launches'], 1) / 1e12},
+            'exact_shortcuts': ['ControlNet hint block evaluated once per hint (t-independent; the reference recomputes it every call)',
+                                'to_k/to_v of the loop-invariant context projected once per sample() call',
+                                'CFG batch cat([x]*2): network prefix up to the first cross-attention evaluated once for both '
+                                'halves (rows are identical there); all three leave every output bit-identical'],
             'kernel_time_ms_est': {k: round(v['ms'] * a.profile_stride, 3) for k, v in prof.items()},
             'whole_path_tflops': value * tflop_per_image * (a.ddim_steps / DDIM_STEPS),
             'whole_path_mfma_frac': value * tflop_per_image * (a.ddim_steps / DDIM_STEPS) / (PEAK_TFLOPS * world),

@@ -14,6 +14,7 @@ MAX_CONTROLNETS = 4
 FLAG_USE_ORIGINAL = 1
 FLAG_ONLY_MID_CONTROL = 2
 FLAG_NO_CONTROL = 4
+FLAG_CFG_PAIRS = 8
 
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GEGLU, ACT_QGELU = 0, 1, 2, 3, 4
 OUT_F16, OUT_F32, OUT_F32_NCHW, OUT_F16_T = 0, 1, 2, 3

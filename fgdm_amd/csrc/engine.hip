@@ -948,8 +948,12 @@ struct fgdm_engine {
     }
 
     // SpatialTransformer.forward with one BasicTransformerBlock (attention.py:234-292)
-    int attn_fwd(const Layer& l, const Tensor& x, const Tensor& ctx16, Tensor* out) {
-        const int B = x.B, T = x.H * x.W, C = x.C, d = C / l.heads;
+    // dup: x holds the SHARED half of a CFG batch (rows b and b + B/2 identical so far); the self-attention part runs on
+    // it once, the result is duplicated where the (per-half) context enters, and `out` has 2 * x.B rows
+    int attn_fwd(const Layer& l, const Tensor& x_in, const Tensor& ctx16, Tensor* out, bool dup = false) {
+        Tensor x = x_in, x_full;
+        int B = x.B;
+        const int T = x.H * x.W, C = x.C, d = C / l.heads;
         Tensor g, h, n, qk, vt, a, h2, q2, k2, v2t, f;
         CHK(gnorm(l.gn, x, nullptr, 1e-6f, false, &g));
         CHK(linear(l.pin, g, Epi{}, &h));
@@ -973,6 +977,12 @@ struct fgdm_engine {
         tfree(qk); tfree(vt);
         { Epi e; e.resid = h.p; e.ld_res = C; CHK(linear(l.o1, a, e, &h2)); }
         tfree(a); tfree(h);
+        if (dup) {     // from here on the two halves differ (their contexts do)
+            Tensor f;
+            CHK(dup_rows(h2, &f)); tfree(h2); h2 = f;
+            CHK(dup_rows(x, &x_full)); x = x_full;
+            B *= 2;
+        }
         // --- attn2 (cross, 77-token context)
         CHK(lnorm(l.ln2, h2, &n));
         CHK(linear(l.q2, n, Epi{}, &q2));
@@ -1007,6 +1017,40 @@ struct fgdm_engine {
         tfree(f); tfree(h);
         { Epi e; e.resid = x.p; e.ld_res = C; CHK(linear(l.pout, h2, e, out)); }
         tfree(h2);
+        if (x_full.p) tfree(x_full);
+        return FGDM_OK;
+    }
+
+    // [x] -> [x; x]: the two halves of a classifier-free-guidance batch share everything up to the first cross-attention
+    int dup_rows(const Tensor& h, Tensor* full) {
+        *full = talloc(2 * h.B, h.H, h.W, h.C);
+        if (!full->p) return fail(FGDM_ERR_NOMEM, "workspace");
+        const size_t bytes = h.numel() * sizeof(half_t);
+        HIP_TRY(hipMemcpyAsync(full->p, h.p, bytes, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync((char*)full->p + bytes, h.p, bytes, hipMemcpyDeviceToDevice, s));
+        return FGDM_OK;
+    }
+    // block_fwd for a block whose input is the SHARED half batch (FGDM_FLAG_CFG_PAIRS): layers run on B/2 rows until the
+    // context enters (attn2 of the first SpatialTransformer); the output has the full 2 * (B/2) rows.
+    int block_fwd_shared(const Block& blk, Tensor xh, bool own_x, const EmbCtx& ec, const Tensor& ctx16, Tensor* out) {
+        Tensor cur = xh;
+        bool own = own_x, full = false;
+        for (size_t j = 0; j < blk.size(); ++j) {
+            const Layer& l = blk[j];
+            Tensor nxt;
+            switch (l.type) {
+                case L_CONV: CHK(conv3(l.conv, cur, nullptr, 1, false, Epi{}, &nxt)); break;
+                case L_RES: CHK(res_fwd(l, cur, nullptr, ec, &nxt)); break;
+                case L_ATTN: CHK(attn_fwd(l, cur, ctx16, &nxt, !full)); full = true; break;
+                case L_DOWN: CHK(conv3(l.conv, cur, nullptr, 2, false, Epi{}, &nxt)); break;
+                case L_UP: CHK(conv3(l.conv, cur, nullptr, 1, true, Epi{}, &nxt)); break;
+            }
+            if (own) tfree(cur);
+            cur = nxt;
+            own = true;
+        }
+        if (!full) { Tensor f; CHK(dup_rows(cur, &f)); if (own) tfree(cur); cur = f; }
+        *out = cur;
         return FGDM_OK;
     }
 
@@ -1144,8 +1188,11 @@ struct fgdm_engine {
     // the UNet's skip tensor hs[i] / h_mid (cldm.py:40,46 + :846), so control residuals never hit HBM separately.
     // fused = false: raw residuals are written as fp32 NCHW into out32 (test entry).
     int controlnet_fwd(Net& n, const Tensor& x4, const int64_t* t, const float* tf, const Tensor& ctx16, const float* scales,
-                       std::vector<Tensor>* hs, Tensor* h_mid, bool only_mid, float* out32, int64_t out_cap) {
+                       std::vector<Tensor>* hs, Tensor* h_mid, bool only_mid, float* out32, int64_t out_cap, bool pairs = false) {
         const int B = x4.B;
+        // CFG pairs: rows b and b + B/2 carry the same x, t and hint -> input blocks 0 and 1 (up to the first
+        // cross-attention) are evaluated once on B/2 rows
+        const bool shared = pairs && !out32 && 2 * n.guided.B == B && n.input.size() > 1;
         if (!n.guided.p) return fail(FGDM_ERR_STATE, "fgdm_set_hint has not been called for this ControlNet");
         if (!(n.guided.B == B || 2 * n.guided.B == B) || n.guided.H != x4.H || n.guided.W != x4.W)
             return fail(FGDM_ERR_ARG, "cached hint does not match the batch / latent size");
@@ -1166,6 +1213,14 @@ struct fgdm_engine {
             Tensor& dst = idx < 0 ? *h_mid : (*hs)[idx];
             if (idx >= 0 && only_mid) return FGDM_OK;
             e.scale = scales ? scales[idx < 0 ? (int)n.input.size() : idx] : 1.f;
+            if (src.B * 2 == dst.B) {      // shared half: the same residual goes into both halves of the UNet's skip tensor
+                for (int half = 0; half < 2; ++half) {
+                    half_t* d = dst.p + (size_t)half * (dst.numel() / 2);
+                    e.resid = d; e.ld_res = dst.C; e.out = d; e.ld_out = dst.C;
+                    CHK(linear(zw, src, e, nullptr));
+                }
+                return FGDM_OK;
+            }
             e.resid = dst.p; e.ld_res = dst.C; e.out = dst.p; e.ld_out = dst.C;
             return linear(zw, src, e, nullptr);
         };
@@ -1174,7 +1229,10 @@ struct fgdm_engine {
             if (i == 0) {
                 // h = conv_in(x) + guided_hint (cldm.py:803-805); a B-sized hint serves both halves of a 2B CFG batch
                 const Layer& l = n.input[0][0];
-                if (n.guided.B == B) {
+                if (shared) {
+                    Tensor xh = x4; xh.B = B / 2;
+                    CHK(block_fwd(n.input[0], xh, false, nullptr, ec, ctx16, n.guided.p, &nxt));
+                } else if (n.guided.B == B) {
                     CHK(block_fwd(n.input[0], x4, false, nullptr, ec, ctx16, n.guided.p, &nxt));
                 } else {
                     nxt = talloc(B, x4.H, x4.W, l.cout);
@@ -1186,6 +1244,8 @@ struct fgdm_engine {
                         CHK(conv3(l.conv, xs, nullptr, 1, false, e, nullptr));
                     }
                 }
+            } else if (shared && i == 1) {
+                CHK(block_fwd_shared(n.input[1], h, true, ec, ctx16, &nxt));    // B/2 rows in, B rows out
             } else {
                 CHK(block_fwd(n.input[i], h, true, nullptr, ec, ctx16, nullptr, &nxt));
             }
@@ -1217,32 +1277,52 @@ struct fgdm_engine {
         EmbCtx ec{emb, n.emb_total};
 
         const bool use_adapter = n.has_adapter && !(flags & FGDM_FLAG_USE_ORIGINAL);
+        // FGDM_FLAG_CFG_PAIRS: the batch is cat([x] * 2) of a classifier-free-guidance step (ddim.py:222-226): rows b and
+        // b + B/2 have the same x, t (and pcond / hint) and differ only in the context.  Everything before the first
+        // cross-attention -- conv_in, the first ResBlock, the first self-attention, the adapter -- is computed once on
+        // B/2 rows and duplicated where the context enters.  Per-sample results are unchanged bit for bit.
+        const bool pairs = (flags & FGDM_FLAG_CFG_PAIRS) && (B % 2 == 0) && n.input.size() > 1;
+        const int Bs = pairs ? B / 2 : B;              // rows of the shared prefix
+        Tensor x4s = x4; x4s.B = Bs;
         Tensor fa[4];
         if (use_adapter) {
             if (pcond) {
-                Tensor p4 = talloc(B, H, W, 4);
+                Tensor p4 = talloc(Bs, H, W, 4);
                 if (!p4.p) return fail(FGDM_ERR_NOMEM, "workspace");
-                if (nchw_f32_to_nhwc_f16(pcond, p4.p, B, 4, HW, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
+                if (nchw_f32_to_nhwc_f16(pcond, p4.p, Bs, 4, HW, 4, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
                 CHK(n.time_adapter ? time_adapter_fwd(n, p4, ec, fa) : adapter_fwd(n, p4, fa));
                 tfree(p4);
             } else {
-                CHK(n.time_adapter ? time_adapter_fwd(n, x4, ec, fa) : adapter_fwd(n, x4, fa));
+                CHK(n.time_adapter ? time_adapter_fwd(n, x4s, ec, fa) : adapter_fwd(n, x4s, fa));
             }
         }
         // ---- encoder (openaimodel.py:849-858); the adapter feature is added BEFORE the skip is recorded
         std::vector<Tensor> hs;
         Tensor h;
         int k = 0;
+        Tensor h0s;        // input block 0 on the shared rows (CFG pairs)
         for (size_t i = 0; i < n.input.size(); ++i) {
             Tensor nxt;
-            CHK(block_fwd(n.input[i], i == 0 ? x4 : h, false, nullptr, ec, ctx16, nullptr, &nxt));
+            if (pairs && i == 0) {
+                CHK(block_fwd(n.input[0], x4s, false, nullptr, ec, ctx16, nullptr, &h0s));
+                CHK(dup_rows(h0s, &nxt));                                        // the skip tensor hs[0] needs all B rows
+            } else if (pairs && i == 1) {
+                CHK(block_fwd_shared(n.input[1], h0s, true, ec, ctx16, &nxt));   // B/2 rows in, B rows out
+            } else {
+                CHK(block_fwd(n.input[i], i == 0 ? x4 : h, false, nullptr, ec, ctx16, nullptr, &nxt));
+            }
             if (use_adapter && (i + 1) % 3 == 0) {
-                if (k >= 4 || fa[k].numel() != nxt.numel()) return fail(FGDM_ERR_ARG, "adapter feature shape mismatch (latent size must be divisible by 8)");
-                if (n.xad_valid) {   // h = h + fk + fa[adapter_idx] (openaimodel.py:1301-1305): fk first, like the reference's sum order
-                    if (n.xad_sum[k].numel() != nxt.numel()) return fail(FGDM_ERR_ARG, "registered adapter conds do not match this batch / latent size");
-                    if (add_f16(nxt.p, n.xad_sum[k].p, nxt.p, nxt.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
+                // the adapter features cover Bs rows; with CFG pairs each is added to both halves
+                if (k >= 4 || fa[k].numel() * (size_t)(B / Bs) != nxt.numel()) return fail(FGDM_ERR_ARG, "adapter feature shape mismatch (latent size must be divisible by 8)");
+                for (int half = 0; half < B / Bs; ++half) {
+                    half_t* dst = nxt.p + (size_t)half * fa[k].numel();
+                    if (n.xad_valid) {   // h = h + fk + fa[adapter_idx] (openaimodel.py:1301-1305): fk first, like the reference's sum order
+                        if (n.xad_sum[k].numel() != nxt.numel()) return fail(FGDM_ERR_ARG, "registered adapter conds do not match this batch / latent size");
+                        const half_t* xs = n.xad_sum[k].p + (size_t)half * fa[k].numel();
+                        if (add_f16(dst, xs, dst, fa[k].numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
+                    }
+                    if (add_f16(dst, fa[k].p, dst, fa[k].numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
                 }
-                if (add_f16(nxt.p, fa[k].p, nxt.p, nxt.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
                 tfree(fa[k]);
                 ++k;
             }
@@ -1255,7 +1335,7 @@ struct fgdm_engine {
         if (!cns.empty() && !(flags & FGDM_FLAG_NO_CONTROL)) {
             for (size_t c = 0; c < cns.size(); ++c)
                 CHK(controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, &hs, &hm,
-                                   (flags & FGDM_FLAG_ONLY_MID_CONTROL) != 0, nullptr, 0));
+                                   (flags & FGDM_FLAG_ONLY_MID_CONTROL) != 0, nullptr, 0, pairs));
         }
         // ---- decoder (openaimodel.py:868-870): virtual concat [h, skip]
         h = hm;

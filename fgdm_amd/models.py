@@ -184,6 +184,8 @@ class LatentDiffusion(_Buffers):
         flags = _lib.FLAG_NO_CONTROL
         if kwargs.get('use_original', False):
             flags |= _lib.FLAG_USE_ORIGINAL
+        if kwargs.get('cfg_pairs', False):           # set by the samplers for cat([x] * 2) batches
+            flags |= _lib.FLAG_CFG_PAIRS
         # AdaptUNetModel.forward(x, t, context, control=None, conds=None) (openaimodel.py:1263): `control` replaces the
         # adapter's prompt (UNetModel calls it `pcond`), `conds` feed the extra adapters
         if 'conds' in kwargs or getattr(self.engine, '_conds_key', None) is not None:
@@ -297,6 +299,8 @@ class ControlLDM(LatentDiffusion):
         ctx = self._context(cond)
         hints = cond.get('c_concat')
         flags = _lib.FLAG_ONLY_MID_CONTROL if self.only_mid_control else 0
+        if kwargs.get('cfg_pairs', False):           # set by the samplers for cat([x] * 2) batches sharing one hint
+            flags |= _lib.FLAG_CFG_PAIRS
         if hints is None:
             return self.engine.apply_model(x_noisy, t, ctx, flags=flags | _lib.FLAG_NO_CONTROL)
         if self.n_controlnets == 1:

@@ -56,6 +56,10 @@ typedef struct fgdm_config {
 #define FGDM_FLAG_USE_ORIGINAL 1      /* UNetModel.forward_original: skip the adapter (openaimodel.py:818-822) */
 #define FGDM_FLAG_ONLY_MID_CONTROL 2  /* ControlledUnetModel only_mid_control (cldm.py:43-44) */
 #define FGDM_FLAG_NO_CONTROL 4        /* cond['c_concat'] is None branch (cldm.py:842-843) */
+#define FGDM_FLAG_CFG_PAIRS 8         /* the batch is cat([x]*2), cat([t]*2) of a classifier-free-guidance step (ddim.py:222-
+                                       * 226; same pcond, and the cached hint covers B/2 rows): rows b and b + B/2 differ only
+                                       * in the context, so the network up to its first cross-attention runs once on B/2 rows.
+                                       * Results are bit-identical to the call without the flag. */
 
 int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out);
 void fgdm_destroy(fgdm_engine* e);

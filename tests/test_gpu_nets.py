@@ -292,3 +292,31 @@ def test_two_controlnets_sum_of_residuals_vs_oracle():
         assert relerr(want, one) > 1e-2          # the second control model really contributes
     finally:
         m.engine.close()
+
+
+def test_cfg_pairs_shared_prefix_is_bit_identical(small_engine, sd_engine):
+    """FGDM_FLAG_CFG_PAIRS: for a cat([x]*2) classifier-free-guidance batch the network prefix up to the first
+    cross-attention (conv_in, first ResBlock, first self-attention, adapter, ControlNet stem) runs once on B/2 rows.
+    Output must equal the plain evaluation bit for bit."""
+    from fgdm_amd import _lib
+    # UNet + ControlNet (reduced depth), hint shared by both halves
+    xs = gi.get('small/x')[:, :, :32, :32].contiguous()
+    x = torch.cat([xs, xs]).cuda()
+    t = torch.tensor([981, 21, 981, 21]).cuda()
+    ctx = torch.cat([gi.get('small/ctx'), torch.from_numpy(synth.context(2, seed=77))]).cuda()
+    hint = torch.from_numpy(synth.hint(2, res=256, seed=78)).cuda()
+    small_engine.set_hint(0, hint)
+    a = small_engine.apply_model(x, t, ctx, control_scales=gi.CTRL_SCALES).clone()
+    b = small_engine.apply_model(x, t, ctx, control_scales=gi.CTRL_SCALES, flags=_lib.FLAG_CFG_PAIRS)
+    assert torch.equal(a, b)
+    assert not torch.equal(a[:2], a[2:])            # the halves really differ (different contexts)
+    # full SD UNet with the FG-DM adapter, no control
+    xs = gi.get('unet/x16')
+    x = torch.cat([xs, xs]).cuda()
+    ctx = torch.cat([gi.get('unet/ctx'), torch.from_numpy(synth.context(2, seed=79))]).cuda()
+    a = sd_engine.apply_model(x, t, ctx, flags=_lib.FLAG_NO_CONTROL).clone()
+    b = sd_engine.apply_model(x, t, ctx, flags=_lib.FLAG_NO_CONTROL | _lib.FLAG_CFG_PAIRS)
+    assert torch.equal(a, b)
+    a = sd_engine.apply_model(x, t, ctx, flags=_lib.FLAG_NO_CONTROL | _lib.FLAG_USE_ORIGINAL).clone()
+    b = sd_engine.apply_model(x, t, ctx, flags=_lib.FLAG_NO_CONTROL | _lib.FLAG_USE_ORIGINAL | _lib.FLAG_CFG_PAIRS)
+    assert torch.equal(a, b)
