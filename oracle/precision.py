@@ -1,0 +1,73 @@
+"""Precision modes of the CPU oracle.  TEST INFRASTRUCTURE.
+
+  'fp32'      the reference's PyTorch-CPU path: everything fp32.  This is the mode the golden vectors from the imported
+              reference pin (tests/test_oracle_golden.py); every helper below is the identity in it.
+  'autocast'  the reference's CUDA path: ``torch.autocast("cuda")`` fp16 (scripts/txt2img_fgdm_inference.py:212-217),
+              emulated op by op by oracle/autocast.py.  oracle.nn carries the reference's explicit dtype casts
+              (``GroupNorm32``'s ``.type(x.dtype)``, ``h.type(x.dtype)`` ...), which are no-ops in fp32.
+  'engine'    the numerics policy of the HIP engine, stated once here and mirrored by ``st`` / ``wt`` calls in oracle.nn:
+                * weights and every GEMM / conv / attention operand are fp16 (round-to-nearest-even), products are
+                  accumulated in fp32 (MFMA);
+                * a GEMM's fused epilogue -- bias, timestep-embedding row, SiLU / ReLU / GEGLU, ControlNet scale --
+                  is evaluated in fp32 on the accumulator and the result is rounded ONCE to fp16;
+                * a residual / skip / adapter-feature add reads two fp16 tensors, adds in fp32 and rounds to fp16;
+                * GroupNorm(+SiLU) and LayerNorm: fp32 statistics and affine, one rounding to fp16 at the end;
+                * attention: log2(e) d^-1/2 is folded into the to_q weights before their fp16 rounding; scores and the
+                  running max stay fp32; probabilities are rounded to fp16 for the PV product, the normaliser is the
+                  sum of those fp16 probabilities (head dims with a spare MFMA row: 40, 80) or of the fp32 ones (160);
+                * the stacked emb_layers output, the final conv's eps and all sampler state are fp32.
+              Against this mode the engine differs only by fp32 summation order, so whole networks are held to 1e-3.
+"""
+import contextlib
+
+import torch
+
+MODE = 'fp32'
+_wcache = {}
+
+
+def st(x):
+    """A tensor the engine stores to HBM between kernels: fp16 rounding in 'engine' mode, identity otherwise."""
+    if MODE == 'engine':
+        return x.half().float()
+    return x
+
+
+def wt(t, scale=None):
+    """A weight as the engine's packed copy holds it (fp16, optionally pre-multiplied in fp32); cached."""
+    if MODE != 'engine':
+        return t if scale is None else t * scale
+    key = (t.data_ptr(), t.numel(), scale)
+    hit = _wcache.get(key)
+    if hit is None:
+        v = t if scale is None else t * scale
+        hit = (t, v.half().float())
+        _wcache[key] = hit
+    return hit[1]
+
+
+def like(y, x):
+    """``y.type(x.dtype)`` of the reference (GroupNorm32.forward util.py:223-225, UNetModel.forward
+    openaimodel.py:803,880): a no-op unless the autocast emulation gave x a lower-precision dtype."""
+    return y if y.dtype == x.dtype else y.to(x.dtype)
+
+
+@contextlib.contextmanager
+def mode(name):
+    """``with precision.mode('engine'):`` / ``'autocast'`` / ``'fp32'``."""
+    global MODE
+    if name not in ('fp32', 'autocast', 'engine'):
+        raise ValueError(name)
+    prev = MODE
+    MODE = name
+    try:
+        if name == 'autocast':
+            from . import autocast
+            with autocast.emulate() as m:
+                yield m
+        else:
+            yield None
+    finally:
+        MODE = prev
+        if name == 'engine':
+            _wcache.clear()

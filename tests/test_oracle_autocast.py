@@ -1,0 +1,134 @@
+"""The oracle's precision modes (oracle/precision.py) on CPU.
+
+  * 'autocast' (the reference's CUDA fp16 policy, oracle/autocast.py) is pinned against tests/golden/*_ac.npz: the
+    REFERENCE's own modules run under the same emulated policy by tools/make_goldens.py.  Those goldens and the fp32
+    goldens give the FLOOR f = |reference(autocast) - reference(fp32)| / |reference(fp32)|: how far the reference's own
+    GPU numerics sit from its PyTorch-CPU path.  The GPU parity tests quote their tolerances in units of f.
+  * fp16 storage makes a deep network chaotic at the 1e-3 level: changing nothing but the ORDER of fp32 sums inside the
+    convolutions (a numerical no-op: 1e-7 in fp32 mode) moves the autocast-mode output by about as much as f itself,
+    because every fp16 rounding turns a perturbation delta into sqrt(delta * ulp).  test_fp16_storage_is_chaotic holds
+    that as a tested number: no two fp16 evaluations that differ in summation order (CPU vs MFMA) can agree to 1e-3 on
+    a whole network; they agree per kernel and per block (tests/test_gpu_ops.py, tests/test_gpu_blocks.py).
+  * 'engine' (the HIP engine's storage policy) is checked for what it must be: as close to fp32 as the autocast policy.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from common import gold, params, relerr
+from oracle import arch, nn as onn, precision
+
+# shallow blocks (a handful of roundings): the same torch CPU kernels on both sides -> equal up to rare rounding flips
+BLOCK_TOL = 3e-4
+
+
+def _floor(name, key):
+    return relerr(gold(name + '_ac')[key].astype(np.float32), gold(name)[key])
+
+
+def _block_params(shapes_fn, tag):
+    sh = {}
+    shapes_fn(sh)
+    return params(sh, tag + '.')
+
+
+@pytest.mark.parametrize('tag,cin,cout', [('res_320_320', 320, 320), ('res_320_640', 320, 640),
+                                           ('res_2560_1280', 2560, 1280), ('res_960_320', 960, 320)])
+def test_resblock_autocast(tag, cin, cout):
+    g = gold('ops_ac')
+    p = _block_params(lambda sh: arch._res_params(sh, '', cin, cout, 1280), tag)
+    with precision.mode('autocast'):
+        y = onn.resblock(p, tag + '.', gi.get(f'ops/{tag}_x'), gi.get('ops/emb'))
+    assert str(y.dtype).endswith(str(g[tag + '_y'].dtype))      # same type promotion as the reference (fp32 x + fp16 h -> fp32)
+    assert relerr(y, g[tag + '_y'].astype(np.float32)) < BLOCK_TOL
+
+
+def test_transformer_blocks_autocast():
+    g = gold('ops_ac')
+    ctx = gi.get('ops/ctx')
+    sh = {}
+    arch._attn_params(sh, '', 640, 768)
+    p = params(sh, 'st.')
+    with precision.mode('autocast'):
+        y = onn.spatial_transformer(p, 'st.', gi.get('ops/st_x'), ctx, 8)
+    assert relerr(y, g['st_y'].astype(np.float32)) < BLOCK_TOL
+    sh = {}
+    arch._attn_params(sh, '', 320, 768)
+    p = params({k[len('transformer_blocks.0.'):]: v for k, v in sh.items() if k.startswith('transformer_blocks.0.')}, 'tblock.')
+    with precision.mode('autocast'):
+        y = onn.transformer_block(p, 'tblock.', gi.get('ops/ff_x'), ctx, 8)
+    assert relerr(y, g['tblock_y'].astype(np.float32)) < BLOCK_TOL
+
+
+def _nets():
+    """(label, golden file, key, callable(oracle) -> tensor)"""
+    t_full = torch.tensor([981, 1])
+    ctx = gi.get('unet/ctx')
+    pu = lambda adapter: params(arch.unet_param_shapes(gi.SD_CFG, adapter=adapter), 'model.diffusion_model.')
+    yield ('SD UNet forward_original 16x16', 'unet_full', 'eps_orig16',
+           lambda: onn.unet_forward(pu(False), gi.SD_CFG, gi.get('unet/x16'), t_full, ctx, prefix='model.diffusion_model.'))
+    yield ('SD UNet + FG-DM adapter 8x8', 'unet_full', 'eps_fgdm8',
+           lambda: onn.unet_forward(pu(True), gi.SD_CFG, gi.get('unet/x8'), t_full, ctx, prefix='model.diffusion_model.',
+                                    use_adapter=True))
+
+    def cldm():
+        p = pu(False)
+        p.update(params(arch.controlnet_param_shapes(gi.SD_CFG), 'control_model.'))
+        return onn.control_ldm_apply(p, gi.SD_CFG, gi.get('cn/x'), torch.tensor([981, 21]), gi.get('cn/ctx'),
+                                     [gi.hint(2, 64, 45)], scales=gi.CTRL_SCALES)
+    yield ('ControlLDM.apply_model 8x8 (full width)', 'controlnet_full', 'eps_ctrl', cldm)
+
+
+@pytest.mark.parametrize('case', list(_nets()), ids=lambda c: c[0])
+def test_whole_networks_autocast_mode_and_floor(case):
+    label, name, key, run = case
+    g32, gac = gold(name)[key], gold(name + '_ac')[key].astype(np.float32)
+    floor = relerr(gac, g32)
+    with torch.no_grad():
+        with precision.mode('autocast'):
+            y = run()
+        with precision.mode('engine'):
+            ye = run()
+    e_pin = relerr(y, gac)
+    e_eng = relerr(ye, g32)
+    print(f'{label}: floor |ref_autocast - ref_fp32| = {floor:.3e}; oracle[autocast] vs ref_autocast = {e_pin:.3e}; '
+          f'oracle[engine] vs ref_fp32 = {e_eng:.3e}')
+    assert 3e-4 < floor < 6e-3           # the reference's own fp16 path is NOT within 1e-3 of its fp32 path ...
+    # same casts, same CPU kernels -> normally exactly 0; on another CPU the fp32 summation order may differ, and then
+    # the two decorrelate to ~sqrt(2) x floor (see test_fp16_storage_is_chaotic)
+    assert e_pin < 1.6 * floor
+    assert e_eng < 1.25 * floor          # the engine's policy (fewer roundings) is no farther from fp32 than autocast's
+
+
+def test_fp16_storage_is_chaotic():
+    cfg = gi.SMALL_CFG
+    p = params(arch.unet_param_shapes(cfg, adapter=False), 'small.')
+    x = gi.get('small/x')[:, :, :32, :32].contiguous()
+    t, ctx = torch.tensor([801, 801]), gi.get('small/ctx')
+    out = {}
+    with torch.no_grad():
+        for mode in ('fp32', 'autocast', 'engine'):
+            for reorder in (False, True):
+                onn.REORDER_FP32_SUMS = reorder
+                try:
+                    with precision.mode(mode):
+                        out[mode, reorder] = onn.unet_forward(p, cfg, x, t, ctx, prefix='small.').float()
+                finally:
+                    onn.REORDER_FP32_SUMS = False
+    noop = relerr(out['fp32', True], out['fp32', False])
+    floor = relerr(out['autocast', False], out['fp32', False])
+    chaos_ac = relerr(out['autocast', True], out['autocast', False])
+    chaos_en = relerr(out['engine', True], out['engine', False])
+    print(f'fp32 sums reordered: fp32 mode {noop:.2e}; autocast mode {chaos_ac:.2e}; engine mode {chaos_en:.2e}; '
+          f'fp16 floor vs fp32 {floor:.2e}')
+    assert noop < 1e-5                       # a numerical no-op ...
+    assert chaos_ac > 3e-4 and chaos_en > 3e-4   # ... that an fp16-storage network amplifies to the 1e-3 level
+    assert chaos_ac < 2 * floor and chaos_en < 2 * floor
+
+
+def test_ddim_trajectory_floor():
+    """10 DDIM steps, CFG 7.5: the reference sampler over the reference UNet, autocast policy vs fp32."""
+    f = _floor('sampler_unet', 'out')
+    print(f'10-step DDIM trajectory: |ref_autocast - ref_fp32| = {f:.3e}')
+    assert 3e-4 < f < 2e-2

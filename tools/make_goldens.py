@@ -91,7 +91,11 @@ def ref_cfg(cfg, **extra):
     return d
 
 
+AC_SUFFIX = ''        # '_ac' while a generator runs under the CUDA-autocast emulation (oracle/autocast.py)
+
+
 def save(name, **arrs):
+    name = name + AC_SUFFIX
     out = {}
     for k, v in arrs.items():
         if isinstance(v, torch.Tensor):
@@ -567,20 +571,38 @@ ALL = dict(schedule=g_schedule, ddpm_schedule=g_ddpm_schedule, param_keys=g_para
            samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip, adapt_unet=g_adapt_unet)
 
 
+# generators that are ALSO run with the reference's modules under the emulated torch.autocast("cuda") policy
+# (scripts/txt2img_fgdm_inference.py:212-217 wraps the whole sampling loop in it) -> tests/golden/<name>_ac.npz
+AC = ('ops', 'unet_full', 'controlnet_full', 'small_nets', 'sampler_unet', 'adapt_unet')
+
+
 def main():
+    global AC_SUFFIX
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
+    ap.add_argument('--ac', action='store_true', help='only the autocast-policy variants (<name>_ac.npz)')
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit(f'reference checkout not found at {REF}; goldens can only be regenerated in the build container')
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
     torch.set_num_threads(os.cpu_count() or 1)
+    from oracle import autocast
     for name, fn in ALL.items():
         if a.only and a.only != name:
             continue
-        print(f'== {name}')
-        fn()
+        if not a.ac:
+            print(f'== {name}')
+            fn()
+        if name in AC:
+            print(f'== {name} under the autocast policy')
+            AC_SUFFIX = '_ac'
+            try:
+                with autocast.emulate() as mode:
+                    fn()
+                print('   ', mode.stats)
+            finally:
+                AC_SUFFIX = ''
 
 
 if __name__ == '__main__':
