@@ -6,6 +6,10 @@ SD-v1.5 UNet + one ControlNet, latent 64x64, hint 512x512, inputs already reside
 every rank samples its own 16 prompts (global x_T / contexts / hints are generated once and sliced), no
 collective inside the loop; frozen weights are generated on rank 0 and broadcast over RCCL before timing.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child
+`python -m torch.distributed.run --nproc-per-node N ... bench.py ...`, before this process touches the GPU), relays rank
+0's JSON line and exits with the children's status.  Under an external torchrun the environment decides.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
 implicit-GEMM family, timed with HIP events on the launch stream inside the timed region) and
 `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N=1 only).
@@ -13,6 +17,8 @@ implicit-GEMM family, timed with HIP events on the launch stream inside the time
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,21 +41,63 @@ def log(msg):
     print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
 
-def build_model(rank, world, first_stage=True, n_controlnets=1):
+def build_model(rank, world, device, first_stage=True, n_controlnets=1):
     """ControlLDM mirror (reference API) over the HIP engine; frozen weights are generated on rank 0 only and
-    shipped with ONE RCCL broadcast of a flat fp32 buffer (fgdm_amd/dist.py)."""
+    shipped with ONE RCCL broadcast of a flat buffer (fp16 where the engine keeps fp16; fgdm_amd/dist.py)."""
     from fgdm_amd import dist as fd, models, synth
     t0 = time.time()
     model = models.ControlLDM(None, n_controlnets=n_controlnets, device=torch.cuda.current_device(),
                               first_stage_config=True if first_stage else None)
     shapes = model.engine.param_shapes()
-    sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, 'cuda')
+    timing = {}
+    sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, device, timing)
     missing, _ = model.load_state_dict(sd, strict=True)
     assert not missing
-    n_params = flat.numel()
+    n_params = sum(int(np.prod(s)) for s in shapes.values())
     del sd, flat
     torch.cuda.empty_cache()
-    return model, n_params, time.time() - t0
+    timing['load_s'] = time.time() - t0
+    return model, n_params, timing
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script on this node (one process per GPU) and wait for them.  Runs BEFORE anything in
+    this process has touched the GPU; the children are fresh processes, nothing is re-exec'ed."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    log(f'--gpus {n}: starting {n} ranks: {" ".join(cmd)}')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes on this pool)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+class DryRunModel:
+    """--dry-run: CPU rehearsal of the launcher / sharding / broadcast / timing plumbing with the analytic stand-in model
+    and the torch stand-ins of the sampler kernels that the CPU test-suite uses (tests/test_samplers_host.py,
+    tests/kernel_stubs.py).  Nothing of the product is measured; the JSON line says "dry_run": true."""
+
+    @staticmethod
+    def build(rank, world):
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import kernel_stubs
+        from fgdm_amd import dist as fd, models, samplers, synth
+        from test_samplers_host import AnalyticLDM
+        samplers._k = kernel_stubs
+        models._k = kernel_stubs
+        shapes = {'model.diffusion_model.time_embed.0.weight': (1280, 320), 'model.diffusion_model.time_embed.0.bias': (1280,),
+                  'model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight': (320, 320)}
+        timing = {}
+        make = synth.make_tensor if rank == 0 else (lambda k, s: np.full(s, np.nan, np.float32))
+        sd, _ = fd.broadcast_weights(shapes, make, rank, world, 'cpu', timing)
+        for k, s in shapes.items():      # every rank must hold rank 0's bytes
+            want = torch.from_numpy(synth.make_tensor(k, s)).to(sd[k].dtype)
+            assert torch.equal(sd[k], want), k
+        timing['load_s'] = 0.0
+        return AnalyticLDM(), sum(int(np.prod(s)) for s in shapes.values()), timing
 
 
 def cpu_baseline():
@@ -105,37 +153,67 @@ def main():
     ap.add_argument('--profile-stride', type=int, default=7,
                     help='HIP-event bracket every n-th kernel launch of the timed region (coprime with the 830 launches per '
                          'evaluation, so every layer shape is sampled uniformly); 1 = every launch')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='torch.distributed backend: nccl (= RCCL over xGMI, the product) or gloo (CPU rehearsal with --dry-run)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU rehearsal of the N-rank plumbing with an analytic stand-in model (tests); measures nothing')
     a = ap.parse_args()
+
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))       # nothing has touched the GPU yet
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if a.gpus != world and world > 1:
-        print(f'warning: --gpus {a.gpus} != WORLD_SIZE {world}; using WORLD_SIZE', file=sys.stderr)
-    torch.cuda.set_device(local)
+    if a.gpus != world:
+        print(f'warning: --gpus {a.gpus} != WORLD_SIZE {world}; the launcher decides: {world} ranks', file=sys.stderr)
+    if a.dry_run and a.backend != 'gloo':
+        sys.exit('--dry-run is a CPU rehearsal: use --backend gloo')
+    if a.backend == 'gloo' and not a.dry_run:
+        sys.exit('--backend gloo only exists for --dry-run: the product path needs the GPUs (there is no CPU fallback)')
+    dev = 'cpu' if a.dry_run else 'cuda'
+    if not a.dry_run:
+        torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
 
+    if os.environ.get('FGDM_BENCH_FAIL_RANK') == str(rank):     # tests: a dying rank must fail the whole launch
+        sys.exit(3)
     from fgdm_amd import synth
     from fgdm_amd import samplers
-    model, n_params, load_s = build_model(rank, world, first_stage=not a.no_first_stage, n_controlnets=a.controlnets)
-    engine = model.engine
-    sampler = samplers.ControlDDIMSampler(model)       # drop-in for controlnet/cldm/ddim_hacked.py:DDIMSampler
+    if a.dry_run:
+        model, n_params, wt = DryRunModel.build(rank, world)
+        engine = None
+        sampler = samplers.DDIMSampler(model)
+    else:
+        model, n_params, wt = build_model(rank, world, dev, first_stage=not a.no_first_stage, n_controlnets=a.controlnets)
+        engine = model.engine
+        sampler = samplers.ControlDDIMSampler(model)       # drop-in for controlnet/cldm/ddim_hacked.py:DDIMSampler
+    load_s = wt['load_s']
 
     npg = a.prompts
     N = npg * world
     sl = slice(rank * npg, (rank + 1) * npg)
-    x_T = torch.from_numpy(synth.latents(N, LATENT, LATENT, seed=42)[sl]).cuda()
-    cond = torch.from_numpy(synth.context(N, seed=43)[sl]).cuda()
-    uncond = torch.from_numpy(synth.context(N, seed=44)[sl]).cuda()
-    hints = [torch.from_numpy(synth.hint(N, 512, seed=45 + k)[sl]).cuda() for k in range(a.controlnets)]
-    # the call the reference makes at controlnet/initialize_cn.py:86-96 (guess_mode=False: control on both branches)
-    c_cond = {'c_concat': hints, 'c_crossattn': [cond]}
-    c_uncond = {'c_concat': hints, 'c_crossattn': [uncond]}
+    lat = 8 if a.dry_run else LATENT
+    x_T = torch.from_numpy(synth.latents(N, lat, lat, seed=42)[sl]).to(dev)
+    cond0 = torch.from_numpy(synth.context(N, seed=43)[sl]).to(dev)
+    uncond0 = torch.from_numpy(synth.context(N, seed=44)[sl]).to(dev)
+    hints0 = [torch.from_numpy(synth.hint(N, 8 * lat, seed=45 + k)[sl]).to(dev) for k in range(a.controlnets)]
 
     def one_step():
+        # every sampling gets FRESH hint / context tensors, as a new batch of images would: the ControlNet hint block
+        # (once per image) and the K/V projections of the conditioning (once per sample() call) are therefore computed
+        # inside the timed region -- the engine's caches are keyed on tensor identity
+        hints = [h.clone() for h in hints0]
+        cond, uncond = cond0.clone(), uncond0.clone()
+        if a.dry_run:
+            return sampler.sample(a.ddim_steps, npg, (4, lat, lat), conditioning=cond, verbose=False, eta=0.0, x_T=x_T,
+                                  unconditional_guidance_scale=CFG_SCALE, unconditional_conditioning=uncond)[0]
+        # the call the reference makes at controlnet/initialize_cn.py:86-96 (guess_mode=False: control on both branches)
+        c_cond = {'c_concat': hints, 'c_crossattn': [cond]}
+        c_uncond = {'c_concat': hints, 'c_crossattn': [uncond]}
         out, _ = sampler.sample(a.ddim_steps, npg, (4, LATENT, LATENT), c_cond, verbose=False, eta=0.0, x_T=x_T,
                                 unconditional_guidance_scale=CFG_SCALE, unconditional_conditioning=c_uncond)
         return out
@@ -143,7 +221,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not a.dry_run:
+            torch.cuda.synchronize()
 
     if rank == 0:
         log(f'weights ready ({n_params / 1e9:.2f} G params, {load_s:.1f} s); warm-up x{a.warmup} ...')
@@ -152,18 +231,38 @@ def main():
     barrier()
     if rank == 0:
         log(f'timing {a.steps} step(s) of {a.ddim_steps} DDIM steps x {npg} prompts per GPU ...')
-    engine.profile_begin(a.profile_stride)
+    if engine is not None:
+        engine.profile_begin(a.profile_stride)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = one_step()
+    if not a.dry_run:
+        torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0        # this rank's own time (before it waits for the others)
     barrier()
     dt = time.perf_counter() - t0
-    prof = engine.profile_end()
+    prof = engine.profile_end() if engine is not None else None
+    per_rank = [npg * a.steps / dt_own]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        rates = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(rates, torch.tensor([npg * a.steps / dt_own], dtype=torch.float64, device=dev))
+        per_rank = [float(r.item()) for r in rates]
     assert torch.isfinite(out).all(), 'non-finite latents'
+    if a.dry_run:
+        if rank == 0:
+            print(json.dumps({'metric': '512x512 images/sec @ 50 DDIM steps, seg-ControlNet+CFG', 'dry_run': True, 'value': None,
+                              'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'backend': a.backend,
+                              'ms_per_step': dt / a.steps * 1e3, 'scaling': 'weak', 'per_rank_images_per_s': per_rank,
+                              'weights': {'params': n_params, 'bcast_s': wt.get('bcast_s'), 'bcast_bytes': wt.get('bcast_bytes')},
+                              'config': {'workload': 'DRY RUN: analytic stand-in model on CPU, launcher/shard/broadcast rehearsal only',
+                                         'prompts_per_gpu': npg}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # outside the timed region (VAE decode excluded from the metric, reported separately):
     # decode_first_stage of this rank's latents to 512x512 images
     dec_s = None
@@ -212,8 +311,9 @@ def main():
                          'timed_launches': ig['launches'], 'launch_sampling_stride': a.profile_stride,
                          'avg_launch_us': ig['ms'] * 1e3 / max(ig['launches'], 1),
                          'algorithmic_tflop_per_launch': ig['work'] / max(ig['launches'], 1) / 1e12},
-            'exact_shortcuts': ['ControlNet hint block evaluated once per hint (t-independent; the reference recomputes it every call)',
-                                'to_k/to_v of the loop-invariant context projected once per sample() call',
+            'exact_shortcuts': ['ControlNet hint block evaluated once per image batch, INSIDE the timed region (t-independent; the '
+                                'reference recomputes it every call)',
+                                'to_k/to_v of the loop-invariant context projected once per sample() call, inside the timed region',
                                 'CFG batch cat([x]*2): network prefix up to the first cross-attention evaluated once for both '
                                 'halves (rows are identical there); all three leave every output bit-identical'],
             'kernel_time_ms_est': {k: round(v['ms'] * a.profile_stride, 3) for k, v in prof.items()},
@@ -226,7 +326,12 @@ def main():
                 'ms_per_image': dec_s / npg * 1e3, 'images_per_s_including_decode': N / (dt / a.steps + dec_s),
                 'note': 'AutoencoderKL.decode of the sampled latents in the same engine, outside the timed region; '
                         '1.27 TFLOP/image'},
-            'weights': {'params': n_params, 'load_s': round(load_s, 2)},
+            'per_rank_images_per_s': per_rank,
+            'weights': {'params': n_params, 'load_s': round(load_s, 2), 'bcast_s': wt.get('bcast_s'),
+                        'bcast_bytes': wt.get('bcast_bytes'),
+                        'note': 'one broadcast of a flat buffer from rank 0 (RCCL over xGMI): fp16 for the tensors the engine '
+                                'stores as fp16, fp32 for biases / norm affine / to_q; load_s includes generating the synthetic '
+                                'weights on rank 0 and repacking on every rank'},
             'workspace': engine.workspace_stats(),
         }
         log(f'{value:.3f} images/s; igemm {achieved:.0f} TFLOP/s')

@@ -54,6 +54,7 @@ SIGNATURES = {
     'fgdm_set_context': (_i, [_p, _p, _i, _p]),
     'fgdm_apply_model': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     'fgdm_clip_encode': (_i, [_p, _p, _i, _i, _p, _p]),
+    'fgdm_run_block': (_i, [_p, C.c_char_p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _i64, C.POINTER(_i64), _p]),
     'fgdm_vae_decode': (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
     'fgdm_image_to_uint8': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     'fgdm_resize_linear_uint8': (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
@@ -73,6 +74,7 @@ SIGNATURES = {
     'fgdm_op_linear': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     'fgdm_debug_force_igemm_cfg': (_i, [_i]),
     'fgdm_bench_igemm': (_i, [_i] * 13 + [C.POINTER(_f)]),
+    'fgdm_bench_norm': (_i, [_i] * 7 + [C.POINTER(_f)]),
     'fgdm_op_groupnorm': (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _f, _i, _p, _p]),
     'fgdm_op_layernorm': (_i, [_p, _i, _i, _p, _p, _f, _p, _p]),
     'fgdm_op_attention': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -284,10 +284,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 }
 
 int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* Vt, int ldvt, half_t* O,
-                     int ldo, int B, int H, int T, int Tk, int d, hipStream_t s) {
+                     int ldo, int B, int H, int T, int Tk, int d, int q_prescaled, hipStream_t s) {
     if (B <= 0 || H <= 0 || T <= 0 || Tk <= 0) return FGDM_ERR_ARG;
     if (ldvt < (Tk + 63) / 64 * 64 || (ldvt & 7) || (ldq & 7) || (ldk & 7) || (ldo & 3)) return FGDM_ERR_ARG;
-    const float sl2e = 1.4426950408889634f / sqrtf((float)d);
+    // q_prescaled: the to_q weights were packed with log2(e) d^-1/2 folded in (fgdm_finalize_weights), so Q arrives in the
+    // log2 domain with ONE fp16 rounding; the kernels then multiply by exactly 1
+    const float sl2e = q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)d);
     const dim3 grid(((T + 127) / 128) * H * B), block(256);
     switch (d) {
         case 40: hipLaunchKernelGGL(attn_kernel<40>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;

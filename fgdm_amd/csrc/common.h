@@ -67,11 +67,13 @@ int layernorm_launch(const half_t* x, int rows, int C, const float* gamma, const
 // ---------------------------------------------------------------- attention
 // O[b, t, h*d + :] = softmax(Q K^T * d^-1/2) V ; Q [B, T, ldq], K [B, Tk, ldk], Vt [B, H*d, ldvt] (keys contiguous)
 int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* Vt, int ldvt,
-                     half_t* O, int ldo, int B, int H, int T, int Tk, int d, hipStream_t s);
+                     half_t* O, int ldo, int B, int H, int T, int Tk, int d, int q_prescaled, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise
 int nchw_f32_to_nhwc_f16(const float* x, half_t* y, int B, int C, int HW, int Cpad, hipStream_t s);
 int f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s);
+int silu_f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s);
+int nhwc_f16_to_nchw_f32(const half_t* x, float* y, int B, int C, int HW, hipStream_t s);
 int im2col3x3(const half_t* x, half_t* A, int B, int H, int W, int C, int stride, int Kpad, hipStream_t s);
 int avgpool2(const half_t* x, half_t* y, int B, int H, int W, int C, hipStream_t s);
 int add_f16(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s);

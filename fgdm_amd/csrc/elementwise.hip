@@ -33,6 +33,28 @@ int f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_f32_to_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, y, n);
     return LAUNCH_OK();
 }
+__global__ void k_nhwc_f16_to_nchw_f32(const half_t* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+    const size_t n = (size_t)B * C * HW;
+    EW_LOOP(i, n) {
+        const int p = (int)(i % HW);
+        const size_t bc = i / HW;
+        const int c = (int)(bc % C);
+        const size_t b = bc / C;
+        y[i] = (float)x[(b * HW + p) * C + c];
+    }
+}
+int nhwc_f16_to_nchw_f32(const half_t* x, float* y, int B, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(k_nhwc_f16_to_nchw_f32, dim3(ew_grid((size_t)B * C * HW)), dim3(EW_BLOCK), 0, s, x, y, B, C, HW);
+    return LAUNCH_OK();
+}
+// y = fp16(SiLU(x)): the `emb_layers` input of a ResBlock (openaimodel.py:238-244) when `emb` is handed in from outside
+__global__ void k_silu_f32_to_f16(const float* __restrict__ x, half_t* __restrict__ y, size_t n) {
+    EW_LOOP(i, n) { const float v = x[i]; y[i] = (half_t)(v / (1.0f + __expf(-v))); }
+}
+int silu_f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_silu_f32_to_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, y, n);
+    return LAUNCH_OK();
+}
 
 // A[m][k], k = tap * C + c (k < 9C), zero for k in [9C, Kpad); 3x3 window, pad 1, given stride.
 // G = channels per thread-granule (8 when C % 8 == 0, else 4 for C == 4)

@@ -34,6 +34,16 @@ struct Arena {
     std::vector<char*> bases;
     size_t slab_bytes = (size_t)4 << 30;
     size_t in_use = 0, peak = 0;
+    // Scope of one C-ABI call: every block handed out while a scope is open is remembered, and whatever is still
+    // allocated when the call fails (an early return somewhere below) is given back by end_scope(true).
+    bool scoped = false;
+    std::vector<void*> live;
+    void begin_scope() { scoped = true; live.clear(); }
+    void end_scope(bool failed) {
+        if (failed) { std::vector<void*> l; l.swap(live); scoped = false; for (void* p : l) release(p); }
+        scoped = false;
+        live.clear();
+    }
 
     ~Arena() { for (char* b : bases) (void)hipFree(b); }
     void* alloc(size_t bytes) {
@@ -50,6 +60,7 @@ struct Arena {
                     s[i].free = false;
                     in_use += bytes;
                     peak = std::max(peak, in_use);
+                    if (scoped) live.push_back(s[i].p);
                     return s[i].p;
                 }
         const size_t sz = std::max(slab_bytes, bytes);
@@ -61,6 +72,7 @@ struct Arena {
     }
     void release(void* p) {
         if (!p) return;
+        if (scoped) { auto it = std::find(live.begin(), live.end(), p); if (it != live.end()) { *it = live.back(); live.pop_back(); } }
         for (auto& s : slabs)
             for (size_t i = 0; i < s.size(); ++i)
                 if (s[i].p == p && !s[i].free) {
@@ -225,7 +237,10 @@ struct fgdm_engine {
     int ctx_B = 0, ctx_T = 0;
     Arena arena;
     half_t* zero = nullptr;
-    std::vector<void*> weight_allocs;
+    // packed weights in HBM, per component (state-dict prefix): re-packing a component frees its previous copy
+    std::unordered_map<std::string, std::vector<void*>> weight_allocs;
+    std::unordered_map<std::string, bool> comp_dirty, comp_packed;
+    std::string cur_comp;
     hipStream_t s = nullptr;      // stream of the call in flight
     Prof prof;
 
@@ -507,25 +522,60 @@ struct fgdm_engine {
         T* d = nullptr;
         if (hipMalloc(&d, std::max<size_t>(h.size() * sizeof(T), 256)) != hipSuccess) return nullptr;
         if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        weight_allocs.push_back(d);
+        weight_allocs[cur_comp].push_back(d);
         return d;
+    }
+    // component (network) a state-dict key belongs to: the longest registered prefix it starts with
+    std::vector<std::string> components() const {
+        std::vector<std::string> c{unet.prefix};
+        for (auto& n : cns) c.push_back(n.prefix);
+        if (vae.on) c.push_back(vae.prefix);
+        if (clip.on) c.push_back(clip.prefix);
+        return c;
+    }
+    std::string component_of(const std::string& key) const {
+        std::string best;
+        for (auto& c : components()) if (key.compare(0, c.size(), c) == 0 && c.size() > best.size()) best = c;
+        return best;
+    }
+    // (re)pack one component if it was never packed or tensors of it were loaded since: the old packed copy is freed
+    template <typename F> int repack(const std::string& comp, F pack) {
+        if (comp_packed[comp] && !comp_dirty[comp]) return FGDM_OK;
+        for (auto& name : order)
+            if (component_of(name) == comp) {
+                const ParamSlot& ps = params[name];
+                if (ps.loaded && ps.host.empty())
+                    return fail(FGDM_ERR_STATE, "tensor " + name + " was released after packing: reload every tensor of " + comp +
+                                                " before finalizing again");
+            }
+        for (void* p : weight_allocs[comp]) (void)hipFree(p);
+        weight_allocs[comp].clear();
+        cur_comp = comp;
+        const int rc = pack();
+        cur_comp.clear();
+        if (rc != FGDM_OK) return rc;
+        comp_packed[comp] = true;
+        comp_dirty[comp] = false;
+        return FGDM_OK;
     }
     // rows: list of (source float*, n_rows) stacked along N; each source is [n][K_src] row-major;
     // kmap(k_packed) -> k_src or -1.  row_perm maps packed row -> stacked source row (GEGLU interleave).
     int pack_rows(GemmW& g, const std::vector<std::pair<const float*, int>>& srcs, int K_src, int K,
-                  const std::vector<int>& kmap, const std::vector<const float*>& biases, bool geglu) {
+                  const std::vector<int>& kmap, const std::vector<const float*>& biases, bool geglu,
+                  const std::vector<float>& src_scale = {}) {
         int N = 0;
         for (auto& s : srcs) N += s.second;
         const size_t npad = igemm_npad(N);
         std::vector<half_t> w(npad * (size_t)K, (half_t)0);
         std::vector<float> bias(npad, 0.f);
         std::vector<const float*> rowp(N);
-        std::vector<float> bflat(N, 0.f);
+        std::vector<float> bflat(N, 0.f), rscale(N, 1.f);
         int r = 0;
         for (size_t si = 0; si < srcs.size(); ++si)
             for (int i = 0; i < srcs[si].second; ++i, ++r) {
                 rowp[r] = srcs[si].first + (size_t)i * K_src;
                 if (si < biases.size() && biases[si]) bflat[r] = biases[si][i];
+                if (si < src_scale.size()) rscale[r] = src_scale[si];      // multiplied in fp32 BEFORE the fp16 rounding
             }
         for (int pr = 0; pr < N; ++pr) {
             int sr = pr;
@@ -534,26 +584,27 @@ struct fgdm_engine {
                 sr = within < 32 ? grp * 32 + within : N / 2 + grp * 32 + (within - 32);
             }
             const float* src = rowp[sr];
+            const float rs = rscale[sr];
             half_t* dst = w.data() + (size_t)pr * K;
-            if (kmap.empty()) for (int k = 0; k < K; ++k) dst[k] = (half_t)src[k];
-            else for (int k = 0; k < K; ++k) if (kmap[k] >= 0) dst[k] = (half_t)src[kmap[k]];
-            bias[pr] = bflat[sr];
+            if (kmap.empty()) for (int k = 0; k < K; ++k) dst[k] = (half_t)(src[k] * rs);
+            else for (int k = 0; k < K; ++k) if (kmap[k] >= 0) dst[k] = (half_t)(src[kmap[k]] * rs);
+            bias[pr] = bflat[sr] * rs;
         }
         g.N = N; g.K = K; g.k_real = K_src;
         g.w = upload(w);
         g.bias = upload(bias);
         return (g.w && g.bias) ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed while packing weights");
     }
-    int pack_linear(GemmW& g, const std::string& pre, bool has_bias, bool geglu = false) {
+    int pack_linear(GemmW& g, const std::string& pre, bool has_bias, bool geglu = false, float wscale = 1.f) {
         const ParamSlot* w = slot(pre + ".weight");
         if (!w) return FGDM_ERR_STATE;
         const ParamSlot* b = has_bias ? slot(pre + ".bias") : nullptr;
         if (has_bias && !b) return FGDM_ERR_STATE;
         const int N = (int)w->shape[0], K = (int)(w->numel() / w->shape[0]);
         if (K & 63) return fail(FGDM_ERR_ARG, "linear K not a multiple of 64: " + pre);
-        return pack_rows(g, {{w->host.data(), N}}, K, K, {}, {b ? b->host.data() : nullptr}, geglu);
+        return pack_rows(g, {{w->host.data(), N}}, K, K, {}, {b ? b->host.data() : nullptr}, geglu, {wscale});
     }
-    int pack_stack(GemmW& g, const std::vector<std::string>& pres, bool has_bias) {
+    int pack_stack(GemmW& g, const std::vector<std::string>& pres, bool has_bias, const std::vector<float>& scales = {}) {
         std::vector<std::pair<const float*, int>> srcs;
         std::vector<const float*> biases;
         int K = 0;
@@ -564,7 +615,7 @@ struct fgdm_engine {
             srcs.push_back({w->host.data(), (int)w->shape[0]});
             if (has_bias) { const ParamSlot* b = slot(pre + ".bias"); if (!b) return FGDM_ERR_STATE; biases.push_back(b->host.data()); }
         }
-        return pack_rows(g, srcs, K, K, {}, biases, false);
+        return pack_rows(g, srcs, K, K, {}, biases, false, scales);
     }
     // conv3x3 [Cout, Cin, 3, 3] -> k = tap * Cin + c (implicit GEMM) or im2col layout with padded Cin / K
     int pack_conv3(GemmW& g, const std::string& pre) {
@@ -619,10 +670,13 @@ struct fgdm_engine {
                     CHK(pack_norm(l.ln1, t + "norm1"));
                     CHK(pack_norm(l.ln2, t + "norm2"));
                     CHK(pack_norm(l.ln3, t + "norm3"));
-                    CHK(pack_stack(l.qk1, {t + "attn1.to_q", t + "attn1.to_k"}, false));
+                    // softmax(q k^T d^-1/2) is evaluated as exp2 of (q log2(e) d^-1/2) k^T: the constant is folded into the
+                    // to_q weights here, in fp32, so the scaled query carries ONE fp16 rounding (attention.py:190-193)
+                    const float qs = 1.4426950408889634f / sqrtf((float)(l.cin / l.heads));
+                    CHK(pack_stack(l.qk1, {t + "attn1.to_q", t + "attn1.to_k"}, false, {qs, 1.f}));
                     CHK(pack_linear(l.v1, t + "attn1.to_v", false));
                     CHK(pack_linear(l.o1, t + "attn1.to_out.0", true));
-                    CHK(pack_linear(l.q2, t + "attn2.to_q", false));
+                    CHK(pack_linear(l.q2, t + "attn2.to_q", false, false, qs));
                     CHK(pack_linear(l.k2, t + "attn2.to_k", false));
                     CHK(pack_linear(l.v2, t + "attn2.to_v", false));
                     CHK(pack_linear(l.o2, t + "attn2.to_out.0", true));
@@ -971,7 +1025,7 @@ struct fgdm_engine {
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
         { char tag[56]; snprintf(tag, sizeof(tag), "attn B%d T%d Tk%d d%d", B, T, T, d);
           prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)T * C, tag);
-          int rc = attention_launch(qk.p, 2 * C, qk.p + C, 2 * C, vt.p, Tp, a.p, C, B, l.heads, T, T, d, s);
+          int rc = attention_launch(qk.p, 2 * C, qk.p + C, 2 * C, vt.p, Tp, a.p, C, B, l.heads, T, T, d, 1, s);
           prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed (unsupported head dim?)"); }
         tfree(qk); tfree(vt);
@@ -1002,7 +1056,7 @@ struct fgdm_engine {
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
         { char tag[56]; snprintf(tag, sizeof(tag), "attn B%d T%d Tk%d d%d", B, T, Tk, d);
           prof.begin(PC_ATTN, s, 4.0 * (double)B * T * (double)Tk * C, tag);
-          int rc = attention_launch(q2.p, C, k2.p, C, v2t.p, Tkp, a.p, C, B, l.heads, T, Tk, d, s);
+          int rc = attention_launch(q2.p, C, k2.p, C, v2t.p, Tkp, a.p, C, B, l.heads, T, Tk, d, 1, s);
           prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed"); }
         tfree(q2);
@@ -1172,6 +1226,98 @@ struct fgdm_engine {
             cur = y;
             if (k % 2 == 1) feats[k / 2] = cur;
         }
+        return FGDM_OK;
+    }
+
+    // One TimestepEmbedSequential (or the FG-DM adapter) of the loaded graph, addressed by its state-dict prefix: the
+    // block-level parity entry (fgdm_run_block)
+    int run_block(const std::string& prefix, const float* x, int C, const float* x_skip, int Cs, const float* emb,
+                  const float* ctx, int B, int H, int W, float* out, int64_t cap, int64_t* out_numel) {
+        if (!finalized) return fail(FGDM_ERR_STATE, "weights not finalized");
+        if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(FGDM_ERR_ARG, "bad shape");
+        Net* net = nullptr;
+        const Block* blk = nullptr;
+        auto scan = [&](Net& n) {
+            auto chk = [&](const Block& b) {
+                if (b.empty() || blk) return;
+                const std::string& lp = b[0].pre;                       // "<block prefix>0."
+                if (lp.size() >= 2 && lp.compare(0, lp.size() - 2, prefix) == 0 && lp.size() - 2 == prefix.size()) { blk = &b; net = &n; }
+            };
+            for (auto& b : n.input) chk(b);
+            chk(n.middle);
+            for (auto& b : n.output) chk(b);
+        };
+        scan(unet);
+        for (auto& n : cns) scan(n);
+        Block single;                // the prefix may also name ONE layer of a block ("...input_blocks.4.1.")
+        if (!blk) {
+            auto scan1 = [&](Net& n) {
+                auto chk = [&](const Block& b) { for (const Layer& l : b) if (single.empty() && l.pre == prefix) { single.push_back(l); net = &n; } };
+                for (auto& b : n.input) chk(b);
+                chk(n.middle);
+                for (auto& b : n.output) chk(b);
+            };
+            scan1(unet);
+            for (auto& n : cns) scan1(n);
+            if (!single.empty()) blk = &single;
+        }
+        const bool adapter = !blk && unet.has_adapter && !unet.time_adapter && prefix == unet.prefix + "adapter.";
+        if (!blk && !adapter) return fail(FGDM_ERR_ARG, "fgdm_run_block: no such block: " + prefix);
+        const int HW = H * W;
+        auto emit = [&](const Tensor& t, int64_t& off) -> int {
+            if (off + (int64_t)t.numel() > cap) return fail(FGDM_ERR_ARG, "fgdm_run_block: output buffer too small");
+            if (nhwc_f16_to_nchw_f32(t.p, out + off, t.B, t.C, t.H * t.W, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
+            off += (int64_t)t.numel();
+            return FGDM_OK;
+        };
+        int64_t off = 0;
+        Tensor xin = talloc(B, H, W, C);
+        if (!xin.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (nchw_f32_to_nhwc_f16(x, xin.p, B, C, HW, C, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
+        if (adapter) {
+            if (C != 4) return fail(FGDM_ERR_ARG, "adapter input has 4 channels");
+            Tensor fa[4];
+            CHK(adapter_fwd(unet, xin, fa));
+            for (int i = 0; i < 4; ++i) { CHK(emit(fa[i], off)); tfree(fa[i]); }
+            tfree(xin);
+            if (out_numel) *out_numel = off;
+            return FGDM_OK;
+        }
+        Tensor xsk, ctx16;
+        if (x_skip) {
+            xsk = talloc(B, H, W, Cs);
+            if (!xsk.p) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (nchw_f32_to_nhwc_f16(x_skip, xsk.p, B, Cs, HW, Cs, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layout kernel");
+        }
+        if ((*blk)[0].cin != C + (x_skip ? Cs : 0) || (C & 63) || (x_skip && (Cs & 63)))
+            return fail(FGDM_ERR_ARG, "fgdm_run_block: channel count does not match the block");
+        bool needs_ctx = false, needs_emb = false;
+        for (const Layer& l : *blk) { needs_ctx |= l.type == L_ATTN; needs_emb |= l.type == L_RES; }
+        if ((needs_ctx && !ctx) || (needs_emb && !emb)) return fail(FGDM_ERR_ARG, "fgdm_run_block: this block needs ctx / emb");
+        if (needs_ctx) {
+            ctx16 = talloc(B, 1, 77, cfg.context_dim);
+            if (!ctx16.p) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
+        }
+        float* emb_all = nullptr;
+        if (needs_emb) {   // emb_layers = SiLU -> Linear on the given `emb` (openaimodel.py:238-244), all ResBlocks in one GEMM
+            const int temb = 4 * cfg.model_channels;
+            Tensor e2 = talloc(1, 1, B, temb);
+            emb_all = (float*)arena.alloc((size_t)B * net->emb_total * sizeof(float));
+            if (!e2.p || !emb_all) return fail(FGDM_ERR_NOMEM, "workspace");
+            if (silu_f32_to_f16(emb, e2.p, e2.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "silu kernel");
+            { Epi e; e.out_kind = OUT_F32; e.out = emb_all; e.ld_out = net->emb_total; e.rps = 1; CHK(linear(net->emb_all, e2, e, nullptr)); }
+            tfree(e2);
+        }
+        EmbCtx ec{emb_all, net->emb_total};
+        Tensor y;
+        CHK(block_fwd(*blk, xin, false, x_skip ? &xsk : nullptr, ec, ctx16, nullptr, &y));
+        CHK(emit(y, off));
+        tfree(y); tfree(xin);
+        if (xsk.p) tfree(xsk);
+        if (ctx16.p) tfree(ctx16);
+        if (emb_all) arena.release(emb_all);
+        if (out_numel) *out_numel = off;
         return FGDM_OK;
     }
 
@@ -1547,6 +1693,15 @@ static int make_desc(const fgdm_config* cfg, fgdm_engine** out) {
     return FGDM_OK;
 }
 
+// One C-ABI call that uses the activation workspace: on a non-OK return everything it still holds goes back to the arena
+template <typename F> static int scoped_call(fgdm_engine* e, void* stream, F f) {
+    e->s = as_stream(stream);
+    e->arena.begin_scope();
+    const int rc = f();
+    e->arena.end_scope(rc != FGDM_OK);
+    return rc;
+}
+
 extern "C" {
 
 static std::string g_create_err;   // why the last fgdm_create failed (there is no engine to ask): fgdm_last_error(NULL)
@@ -1570,7 +1725,7 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
 void fgdm_destroy(fgdm_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->prof.pool) (void)hipEventDestroy(ev);
-    for (void* p : e->weight_allocs) (void)hipFree(p);
+    for (auto& kv : e->weight_allocs) for (void* p : kv.second) (void)hipFree(p);
     if (e->zero) (void)hipFree(e->zero);
     for (auto& n : e->cns) if (n.guided.p) (void)hipFree(n.guided.p);
     e->drop_context();
@@ -1627,6 +1782,7 @@ int fgdm_load_tensor(fgdm_engine* e, const char* key, const void* data, int dtyp
         return e->fail(FGDM_ERR_ARG, "unsupported dtype");
     }
     ps.loaded = true;
+    e->comp_dirty[e->component_of(key)] = true;
     e->finalized = false;
     return FGDM_OK;
 }
@@ -1638,11 +1794,13 @@ int fgdm_finalize_weights(fgdm_engine* e) {
     e->drop_context();          // everything derived from the previous weights is stale
     e->drop_adapter_conds();
     for (auto& n : e->cns) if (n.guided.p) { (void)hipFree(n.guided.p); n.guided = Tensor{}; }
-    rc = e->pack_net(e->unet);
+    // only components whose tensors changed since the last call are packed again (their previous HBM copy is freed
+    // first): loading the base checkpoint and then a ControlNet checkpoint does not re-pack or leak the UNet
+    rc = e->repack(e->unet.prefix, [&] { return e->pack_net(e->unet); });
     if (rc != FGDM_OK) return rc;
-    for (auto& n : e->cns) { rc = e->pack_net(n); if (rc != FGDM_OK) return rc; }
-    if (e->vae.on) { rc = e->pack_vae(); if (rc != FGDM_OK) return rc; }
-    if (e->clip.on) { rc = e->pack_clip(); if (rc != FGDM_OK) return rc; }
+    for (auto& n : e->cns) { rc = e->repack(n.prefix, [&] { return e->pack_net(n); }); if (rc != FGDM_OK) return rc; }
+    if (e->vae.on) { rc = e->repack(e->vae.prefix, [&] { return e->pack_vae(); }); if (rc != FGDM_OK) return rc; }
+    if (e->clip.on) { rc = e->repack(e->clip.prefix, [&] { return e->pack_clip(); }); if (rc != FGDM_OK) return rc; }
     e->finalized = true;
     return FGDM_OK;
 }
@@ -1700,40 +1858,34 @@ int fgdm_workspace_stats(fgdm_engine* e, int64_t* peak_bytes, int64_t* reserved_
 
 int fgdm_set_hint(fgdm_engine* e, int cn, const float* hint, int B, int Hh, int Wh, void* stream) {
     if (!e || !hint) return FGDM_ERR_ARG;
-    e->s = as_stream(stream);
-    return e->set_hint(cn, hint, B, Hh, Wh);
+    return scoped_call(e, stream, [&] { return e->set_hint(cn, hint, B, Hh, Wh); });
 }
 
 int fgdm_apply_model(fgdm_engine* e, const float* x, const int64_t* t, const float* t_float, const float* ctx,
                      const float* pcond, const float* control_scales, int B, int H, int W, int flags, float* eps_out,
                      void* stream) {
     if (!e || !x || (!t && !t_float) || !eps_out) return FGDM_ERR_ARG;
-    e->s = as_stream(stream);
-    return e->apply_model(x, t, t_float, ctx, pcond, control_scales, B, H, W, flags, eps_out);
+    return scoped_call(e, stream, [&] { return e->apply_model(x, t, t_float, ctx, pcond, control_scales, B, H, W, flags, eps_out); });
 }
 
 int fgdm_set_adapter_conds(fgdm_engine* e, const float* const* conds, int n_conds, int B, int H, int W, void* stream) {
     if (!e) return FGDM_ERR_ARG;
-    e->s = as_stream(stream);
-    return e->set_adapter_conds(conds, n_conds, B, H, W);
+    return scoped_call(e, stream, [&] { return e->set_adapter_conds(conds, n_conds, B, H, W); });
 }
 
 int fgdm_set_context(fgdm_engine* e, const float* ctx, int B, void* stream) {
     if (!e || !ctx) return FGDM_ERR_ARG;
-    e->s = as_stream(stream);
-    return e->set_context(ctx, B);
+    return scoped_call(e, stream, [&] { return e->set_context(ctx, B); });
 }
 
 int fgdm_clip_encode(fgdm_engine* e, const int64_t* ids, int B, int T, float* out, void* stream) {
     if (!e || !ids || !out) return FGDM_ERR_ARG;
-    e->s = as_stream(stream);
-    return e->clip_encode(ids, B, T, out);
+    return scoped_call(e, stream, [&] { return e->clip_encode(ids, B, T, out); });
 }
 
 int fgdm_vae_decode(fgdm_engine* e, const float* z, int B, int H, int W, float scale, float* image, void* stream) {
     if (!e || !z || !image) return FGDM_ERR_ARG;
-    e->s = as_stream(stream);
-    return e->vae_decode(z, B, H, W, scale, image);
+    return scoped_call(e, stream, [&] { return e->vae_decode(z, B, H, W, scale, image); });
 }
 
 int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, const float* ctx, int B, int H, int W,
@@ -1741,14 +1893,22 @@ int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, co
     if (!e || !x || !t || !ctx || !out) return FGDM_ERR_ARG;
     if (!e->finalized) return e->fail(FGDM_ERR_STATE, "weights not finalized");
     if (cn < 0 || cn >= (int)e->cns.size()) return e->fail(FGDM_ERR_ARG, "no such ControlNet");
-    e->s = as_stream(stream);
-    Tensor x4 = e->talloc(B, H, W, 4), ctx16 = e->talloc(B, 1, 77, e->cfg.context_dim);
-    if (!x4.p || !ctx16.p) return e->fail(FGDM_ERR_NOMEM, "workspace");
-    if (nchw_f32_to_nhwc_f16(x, x4.p, B, 4, H * W, 4, e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "layout kernel");
-    if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "convert kernel");
-    const int rc = e->controlnet_fwd(e->cns[cn], x4, t, nullptr, ctx16, nullptr, nullptr, nullptr, false, out, out_capacity_floats);
-    e->tfree(x4); e->tfree(ctx16);
-    return rc;
+    return scoped_call(e, stream, [&]() -> int {
+        Tensor x4 = e->talloc(B, H, W, 4), ctx16 = e->talloc(B, 1, 77, e->cfg.context_dim);
+        if (!x4.p || !ctx16.p) return e->fail(FGDM_ERR_NOMEM, "workspace");
+        if (nchw_f32_to_nhwc_f16(x, x4.p, B, 4, H * W, 4, e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "layout kernel");
+        if (f32_to_f16(ctx, ctx16.p, ctx16.numel(), e->s) != FGDM_OK) return e->fail(FGDM_ERR_HIP, "convert kernel");
+        const int rc = e->controlnet_fwd(e->cns[cn], x4, t, nullptr, ctx16, nullptr, nullptr, nullptr, false, out, out_capacity_floats);
+        e->tfree(x4); e->tfree(ctx16);
+        return rc;
+    });
+}
+
+int fgdm_run_block(fgdm_engine* e, const char* prefix, const float* x, int C, const float* x_skip, int Cs, const float* emb,
+                   const float* ctx, int B, int H, int W, float* out, int64_t out_capacity_floats, int64_t* out_numel,
+                   void* stream) {
+    if (!e || !prefix || !x || !out) return FGDM_ERR_ARG;
+    return scoped_call(e, stream, [&] { return e->run_block(prefix, x, C, x_skip, Cs, emb, ctx, B, H, W, out, out_capacity_floats, out_numel); });
 }
 
 int fgdm_ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale, float a_t, float a_prev,
@@ -1797,7 +1957,7 @@ int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* u
     if (!e || !x || !cond || !timesteps || !alphas || !alphas_prev || !sqrt_one_minus_alphas || S <= 0) return FGDM_ERR_ARG;
     if (!e->finalized) return e->fail(FGDM_ERR_STATE, "weights not finalized");
     hipStream_t s = as_stream(stream);
-    e->s = s;
+    return scoped_call(e, stream, [&]() -> int {
     const bool cfg_on = uncond && cfg_scale != 1.0f;
     const int Bm = cfg_on ? 2 * B : B;
     const size_t n = (size_t)B * 4 * H * W, nctx = (size_t)B * 77 * e->cfg.context_dim;
@@ -1828,6 +1988,7 @@ int fgdm_sample_ddim(fgdm_engine* e, float* x, const float* cond, const float* u
     }
     e->arena.release(x2); e->arena.release(eps); e->arena.release(c2); e->arena.release(tdev);
     return rc;
+    });
 }
 
 // ------------------------------------------------------------------------------------ op-level test entries
@@ -1972,6 +2133,50 @@ int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, i
     return rc;
 }
 
+// Micro-benchmark of one GroupNorm / LayerNorm shape on random data: average device ms over `iters` launches.
+// kind 0: GroupNorm32(+SiLU) over [B, HW, C0 (+ C1 virtual concat)]; kind 1: LayerNorm over [B * HW, C0].
+int fgdm_bench_norm(int kind, int B, int HW, int C0, int C1, int silu, int iters, float* avg_ms) {
+    if (!avg_ms || iters <= 0 || B <= 0 || HW <= 0) return FGDM_ERR_ARG;
+    const int C = C0 + C1;
+    const size_t n0 = (size_t)B * HW * C0, n1 = (size_t)B * HW * (size_t)std::max(C1, 1), n = (size_t)B * HW * C;
+    unsigned st = 777u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 9) & 0xffff) / 32768.0f - 1.0f; };
+    std::vector<half_t> h0(n0), h1(n1);
+    for (auto& v : h0) v = (half_t)rnd();
+    for (auto& v : h1) v = (half_t)rnd();
+    std::vector<float> g(C), b(C);
+    for (int i = 0; i < C; ++i) { g[i] = 1.f + 0.2f * rnd(); b[i] = 0.1f * rnd(); }
+    TmpDev tmp;
+    half_t* out = nullptr;
+    float* ws = nullptr;
+    if (hipMalloc(&out, n * sizeof(half_t)) != hipSuccess) return FGDM_ERR_NOMEM;
+    tmp.ptrs.push_back(out);
+    if (hipMalloc(&ws, groupnorm_ws_floats(B, HW) * sizeof(float)) != hipSuccess) return FGDM_ERR_NOMEM;
+    tmp.ptrs.push_back(ws);
+    const half_t* d0 = tmp.up(h0);
+    const half_t* d1 = C1 ? tmp.up(h1) : nullptr;
+    const float* dg = tmp.up(g);
+    const float* db = tmp.up(b);
+    if (!d0 || !dg || !db) return FGDM_ERR_NOMEM;
+    auto run = [&]() {
+        return kind == 0 ? groupnorm_launch(d0, C0, d1, C1, B, HW, dg, db, 1e-5f, silu, out, ws, nullptr)
+                         : layernorm_launch(d0, B * HW, C0, dg, db, 1e-5f, out, nullptr);
+    };
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = FGDM_OK;
+    for (int i = 0; i < 3 && rc == FGDM_OK; ++i) rc = run();
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && rc == FGDM_OK; ++i) rc = run();
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int fgdm_op_groupnorm(const void* x0, int C0, const void* x1, int C1, int B, int HW, const float* gamma, const float* beta,
                       float eps, int silu, void* out, void* stream) {
     if (!x0 || !gamma || !beta || !out) return FGDM_ERR_ARG;
@@ -1990,7 +2195,7 @@ int fgdm_op_layernorm(const void* x, int rows, int C, const float* gamma, const 
 int fgdm_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo, int B,
                       int heads, int T, int Tk, int d, void* stream) {
     if (!q || !k || !vt || !o) return FGDM_ERR_ARG;
-    return attention_launch((const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)vt, ldvt, (half_t*)o, ldo, B, heads, T, Tk, d, as_stream(stream));
+    return attention_launch((const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)vt, ldvt, (half_t*)o, ldo, B, heads, T, Tk, d, 0, as_stream(stream));
 }
 
 }  // extern "C"

@@ -215,9 +215,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
                     for (int e = 0; e < 4; ++e) {
                         const int row = row0 + e;
                         if (row < a.M) {
-                            float x = v[e];
-                            if (a.resid) x += (float)a.resid[(size_t)row * a.ld_res + ocol];
-                            o[(size_t)row * a.ld_out + ocol] = (half_t)x;
+                            // numerics policy (oracle/precision.py): the GEMM result is rounded to fp16, THEN the fp16
+                            // residual is added in fp32 and the sum rounded -- identical in every kernel of the family
+                            half_t x = (half_t)v[e];
+                            if (a.resid) x = (half_t)((float)x + (float)a.resid[(size_t)row * a.ld_res + ocol]);
+                            o[(size_t)row * a.ld_out + ocol] = x;
                         }
                     }
                 } else if (a.out_kind == OUT_F32) {

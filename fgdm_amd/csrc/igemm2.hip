@@ -448,7 +448,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a) {
             if (a.act == ACT_SILU) x = silu_f(x);
             else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
             else if (a.act == ACT_QGELU) x = x / (1.0f + __expf(-1.702f * x));
-            o[e] = (half_t)(x * a.scale + (float)r[e]);
+            const half_t y = (half_t)(x * a.scale);                     // same two roundings as the fused epilogue
+            o[e] = a.resid ? (half_t)((float)y + (float)r[e]) : y;
         }
         *(h4*)((half_t*)a.out + (size_t)row * a.ld_out + col) = o;
     }

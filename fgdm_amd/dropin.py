@@ -7,6 +7,9 @@
     from controlnet.cldm.ddim_hacked import DDIMSampler        # controlnet/initialize_cn.py:16
     from controlnet.cldm.cldm import ControlLDM
     import controlnet.initialize_cn as initialize_cn           # scripts/txt2img_fgdm_inference.py:25 (process, initialize_controlnet)
+    from ldm.util import instantiate_from_config               # scripts/txt2img_fgdm_inference.py:17,27
+    from cldm.model import create_model, load_state_dict       # controlnet/seg2image_inference.py:18 (bare package names)
+    from cldm.ddim_hacked import DDIMSampler                   # controlnet/seg2image_inference.py:19
 
 install() registers lightweight module objects under those dotted names (only the sampling-path modules;
 everything else of the reference's `ldm` / `controlnet` packages is untouched if it is importable).
@@ -15,18 +18,27 @@ If the real reference packages are already imported, install(replace=True) swaps
 import sys
 import types
 
-from . import initialize_cn, models, samplers
+from . import config, initialize_cn, models, samplers, seg2image
 
+_CLDM_MODEL = {'load_state_dict': initialize_cn.load_state_dict, 'get_state_dict': initialize_cn.get_state_dict,
+               'create_model': config.create_model}
 _MAP = {
+    'ldm.util': {'instantiate_from_config': config.instantiate_from_config},              # scripts/txt2img_fgdm_inference.py:17
     'ldm.models.diffusion.ddim': {'DDIMSampler': samplers.DDIMSampler},
     'ldm.models.diffusion.plms': {'PLMSSampler': samplers.PLMSSampler},
     'ldm.models.diffusion.dpm_solver': {'DPMSolverSampler': samplers.DPMSolverSampler},
     'ldm.models.diffusion.ddpm': {'LatentDiffusion': models.LatentDiffusion, 'DiffusionWrapper': models.DiffusionWrapper},
+    'controlnet.ldm.util': {'instantiate_from_config': config.instantiate_from_config},
     'controlnet.cldm.ddim_hacked': {'DDIMSampler': samplers.ControlDDIMSampler},
     'controlnet.cldm.cldm': {'ControlLDM': models.ControlLDM},
-    'controlnet.cldm.model': {'load_state_dict': initialize_cn.load_state_dict, 'get_state_dict': initialize_cn.get_state_dict},
+    'controlnet.cldm.model': _CLDM_MODEL,
     'controlnet.initialize_cn': {'initialize_controlnet': initialize_cn.initialize_controlnet,
                                  'process': initialize_cn.process},
+    # controlnet/seg2image_inference.py runs from inside controlnet/ and imports the bare package names (:18-19)
+    'cldm.model': _CLDM_MODEL,
+    'cldm.ddim_hacked': {'DDIMSampler': samplers.ControlDDIMSampler},
+    'cldm.cldm': {'ControlLDM': models.ControlLDM},
+    'controlnet.seg2image_inference': {'process': seg2image.process, 'setup': seg2image.setup},
 }
 
 

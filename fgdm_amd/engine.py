@@ -27,6 +27,9 @@ def make_config(cfg=None, use_adapter=False, n_controlnets=0, hint_channels=3, w
     """fgdm_config from the reference's UNetModel kwargs (models/config.yaml:33-48); `vae`: None (no first-stage
     decoder), True (SD_VAE) or the AutoencoderKL `ddconfig` dict; `clip`: None, True (SD_CLIP) or a CLIPTextConfig-style
     dict (text encoder in the engine)."""
+    if cfg is not None and ('target' in cfg or any(k not in SD_V1 for k in cfg)):
+        from . import config as _cfgmod          # {target, params} node / OmegaConf / dict with extra UNetModel kwargs
+        cfg = _cfgmod.unet_params(cfg)[1]
     cfg = dict(SD_V1 if cfg is None else cfg)
     c = _lib.FgdmConfig()
     c.in_channels = cfg['in_channels']
@@ -221,7 +224,11 @@ class Engine:
         else:
             t_int = t.to(self.device, torch.int64).contiguous()
         B, Cc, H, W = x.shape
-        assert Cc == 4 and ctx.shape[0] == B and ctx.shape[1] == 77 and t.shape[0] == B
+        if Cc != 4 or ctx.shape[0] != B or t.shape[0] != B:
+            raise ValueError(f'apply_model: x {tuple(x.shape)}, t {tuple(t.shape)}, context {tuple(ctx.shape)} do not agree')
+        if ctx.shape[1] != 77:
+            raise NotImplementedError(f'context of {ctx.shape[1]} tokens: the engine takes one 77-token CLIP context per sample '
+                                      '(several c_crossattn entries concatenated along the token axis are not supported)')
         # The conditioning is the same tensor OBJECT in every denoising step: its to_k / to_v projections are computed
         # once (fgdm_set_context) and reused while that object is unmodified (torch bumps _version on in-place writes;
         # holding the object keeps its storage from being recycled under the same address).
@@ -242,6 +249,8 @@ class Engine:
         else:
             sc_ptr = C.c_void_p(0)
         if pcond is not None:
+            if tuple(pcond.shape) != tuple(x.shape):
+                raise ValueError(f'pcond / control shape {tuple(pcond.shape)} must equal the latent batch {tuple(x.shape)}')
             pcond = pcond.to(self.device, torch.float32).contiguous()
         rc = self.lib.fgdm_apply_model(self.h, _ptr(x), _ptr(t_int), _ptr(t_flt), _ptr(ctx_arg), _ptr(pcond), sc_ptr, B, H, W,
                                        flags, _ptr(eps), _stream())
@@ -266,6 +275,21 @@ class Engine:
         rc = self.lib.fgdm_vae_decode(self.h, _ptr(z), B, H, W, float(scale), _ptr(img), _stream())
         self._check(rc, 'fgdm_vae_decode')
         return img
+
+    def run_block(self, prefix, x, emb=None, ctx=None, x_skip=None):
+        """One block (or one layer of a block, or the FG-DM adapter) of the loaded graph by state-dict prefix, e.g.
+        'model.diffusion_model.input_blocks.4.' / '...input_blocks.4.1.' / 'model.diffusion_model.adapter.'.
+        fp32 NCHW in and out; returns a flat fp32 tensor (the caller knows the block's output shape)."""
+        f32 = lambda v: None if v is None else v.to(self.device, torch.float32).contiguous()
+        x, emb, ctx, x_skip = f32(x), f32(emb), f32(ctx), f32(x_skip)
+        B, Cc, H, W = x.shape
+        cap = 4 * B * 1280 * 4 * H * W            # generous: an Upsample quadruples the pixels
+        out = torch.empty(cap, device=self.device, dtype=torch.float32)
+        n = C.c_int64(0)
+        rc = self.lib.fgdm_run_block(self.h, prefix.encode(), _ptr(x), Cc, _ptr(x_skip), 0 if x_skip is None else x_skip.shape[1],
+                                     _ptr(emb), _ptr(ctx), B, H, W, _ptr(out), cap, C.byref(n), _stream())
+        self._check(rc, f'fgdm_run_block({prefix})')
+        return out[:n.value]
 
     def controlnet(self, cn, x, t, ctx):
         """The 13 ControlNet residuals (fp32 NCHW), for inspection / tests."""

@@ -5,8 +5,9 @@
 
 `process` keeps the reference's signature and host-side types (uint8 numpy in, list of uint8 numpy out) and also accepts
 a device tensor for `input_image` (uint8 NHWC) or a ready hint (fp32 NCHW), so that the two-stage chain can stay on the
-GPU (fgdm_amd/boundary.py).  Text conditioning comes from `model.get_learned_conditioning` exactly as in the reference
-(CLIP itself is outside this path: plug `model.cond_stage_model`)."""
+GPU (fgdm_amd/boundary.py).  Text conditioning comes from `model.get_learned_conditioning` exactly as in the reference: the
+model is built with its cond_stage_config, so the checkpoint's `cond_stage_model.transformer.text_model.*` tensors load into
+the engine's text encoder (fgdm_clip_encode); only the BPE tokenizer stays on the host (`model.tokenizer`)."""
 import os
 import random
 
@@ -39,11 +40,13 @@ def load_state_dict(ckpt_path, location='cpu'):
     return state_dict
 
 
-def initialize_controlnet(cond='seg', state_dict=None, device=0):
-    """-> (ControlLDM mirror, ControlNet DDIMSampler mirror).  `state_dict` overrides reading the checkpoint file."""
+def initialize_controlnet(cond='seg', state_dict=None, device=0, cond_stage_config=True):
+    """-> (ControlLDM mirror, ControlNet DDIMSampler mirror).  `state_dict` overrides reading the checkpoint file;
+    cond_stage_config=None builds the model without the text encoder (then plug `model.cond_stage_model`)."""
     if cond not in CHECKPOINTS:
         raise NotImplementedError
-    model = models.ControlLDM(CLDM_V15, n_controlnets=1, device=device, first_stage_config=True)
+    model = models.ControlLDM(CLDM_V15, n_controlnets=1, device=device, first_stage_config=True,
+                              cond_stage_config=cond_stage_config)
     sd = state_dict if state_dict is not None else load_state_dict(CHECKPOINTS[cond], location='cpu')
     m, u = model.load_state_dict(sd, strict=False)
     print('Missing keys: ', m)
@@ -67,6 +70,9 @@ def process(model, ddim_sampler, input_image, prompt, a_prompt, n_prompt, num_sa
     with torch.no_grad():
         control = _control_from(input_image, model.device)
         B, C, H, W = control.shape
+        if H % 64 or W % 64:          # the reference's annotator.util.resize_image always hands over multiples of 64
+            raise ValueError(f'control image {H}x{W}: height and width must be multiples of 64 (latent of 8 px, three stride-2 '
+                             'levels); resize it first (fgdm_amd.seg2image.resized_shape)')
         control = torch.cat([control for _ in range(num_repeats)], dim=0)
         if seed == -1:
             seed = random.randint(0, 65535)

@@ -18,7 +18,7 @@ import contextlib
 import numpy as np
 import torch
 
-from . import _lib, schedule
+from . import _lib, config as _cfg, schedule
 from . import engine as _k
 
 
@@ -55,11 +55,9 @@ class LatentDiffusion(_Buffers):
             raise NotImplementedError('only eps-parameterization is used by the shipped configs (models/config.yaml)')
         if conditioning_key != 'crossattn':
             raise NotImplementedError("only conditioning_key='crossattn' is on the hot path (models/config.yaml:15)")
-        self.engine = engine if engine is not None else _k.Engine(unet_config, use_adapter=use_adapter,
-                                                                   n_controlnets=n_controlnets, device=device,
-                                                                   num_prompts=num_prompts,
-                                                                   vae=self._ddconfig(first_stage_config),
-                                                                   clip=self._clipconfig(cond_stage_config))
+        self.engine = engine if engine is not None else _k.Engine(device=device, **self.engine_args(
+            unet_config=unet_config, use_adapter=use_adapter, n_controlnets=n_controlnets, num_prompts=num_prompts,
+            first_stage_config=first_stage_config, cond_stage_config=cond_stage_config))
         self.device = self.engine.device
         self.model = DiffusionWrapper(self.engine, conditioning_key)
         self.parameterization = parameterization
@@ -79,6 +77,23 @@ class LatentDiffusion(_Buffers):
                                 linear_end=linear_end, cosine_s=cosine_s, v_posterior=v_posterior,
                                 given_betas=given_betas)
         self._finalized = False
+
+    @classmethod
+    def engine_args(cls, unet_config=None, use_adapter=True, n_controlnets=0, num_prompts=1, first_stage_config=None,
+                    cond_stage_config=None, **ignored):
+        """Constructor arguments of the reference model -> keyword arguments of fgdm_amd.engine.Engine / make_config (a pure
+        function: works without a GPU).  unet_config as the scripts pass it: {target: ...UNetModel, params: {...}}
+        (models/config.yaml:33-48; OmegaConf or dict) or the bare parameter dict; the target and its flags select the
+        adapter variant the engine builds."""
+        kind, cfg, uflags = _cfg.unet_params(unet_config)
+        if kind == 'controlled' or uflags.get('no_prompting'):
+            use_adapter = False                       # ControlledUnetModel / no_prompting: the plain SD UNet
+        elif uflags.get('use_time_adapter'):
+            use_adapter = 'time'
+        if kind == 'adapt' or uflags.get('num_prompts', 1) > 1:
+            num_prompts = max(num_prompts, int(uflags.get('num_prompts', num_prompts)))
+        return dict(cfg=cfg, use_adapter=use_adapter, n_controlnets=n_controlnets, num_prompts=num_prompts,
+                    vae=cls._ddconfig(first_stage_config), clip=cls._clipconfig(cond_stage_config))
 
     @staticmethod
     def _ddconfig(first_stage_config):
@@ -110,6 +125,9 @@ class LatentDiffusion(_Buffers):
 
     # ---- nn.Module-ish surface the scripts touch (scripts/txt2img_fgdm_inference.py:23-38,179-180,216-218)
     def cuda(self, *a, **k):
+        return self
+
+    def cpu(self, *a, **k):          # create_model(...).cpu() (controlnet/cldm/model.py:26): the engine lives on its GPU
         return self
 
     def to(self, *a, **k):
@@ -184,14 +202,27 @@ class LatentDiffusion(_Buffers):
         flags = _lib.FLAG_NO_CONTROL
         if kwargs.get('use_original', False):
             flags |= _lib.FLAG_USE_ORIGINAL
-        if kwargs.get('cfg_pairs', False):           # set by the samplers for cat([x] * 2) batches
-            flags |= _lib.FLAG_CFG_PAIRS
         # AdaptUNetModel.forward(x, t, context, control=None, conds=None) (openaimodel.py:1263): `control` replaces the
         # adapter's prompt (UNetModel calls it `pcond`), `conds` feed the extra adapters
         if 'conds' in kwargs or getattr(self.engine, '_conds_key', None) is not None:
             self.engine.set_adapter_conds(kwargs.get('conds'))
         pcond = kwargs.get('pcond', kwargs.get('control'))
+        # cfg_pairs (set by the samplers for cat([x] * 2) batches): the engine evaluates the network prefix on the first
+        # half only, which is exact only if the two halves of a user-supplied prompt image are the same rows too
+        if kwargs.get('cfg_pairs', False) and (pcond is None or self._halves_equal(pcond)):
+            flags |= _lib.FLAG_CFG_PAIRS
         return self.engine.apply_model(x_noisy, t, self._context(cond), flags=flags, pcond=pcond)
+
+    def _halves_equal(self, v):
+        """True iff v[:B/2] == v[B/2:] (checked once per tensor object / version: the samplers pass the same object every
+        step).  The memo keeps the tensor alive so its id cannot be recycled."""
+        key = (id(v), v._version, tuple(v.shape))
+        memo = getattr(self, '_halves_memo', None)
+        if memo is None or memo[0] != key:
+            n = v.shape[0]
+            eq = n % 2 == 0 and bool(torch.equal(v[:n // 2], v[n // 2:]))
+            self._halves_memo = memo = (key, v, eq)
+        return memo[2]
 
     # ---- closed-form pieces
     def _at(self, name, t):
@@ -278,14 +309,34 @@ class ControlLDM(LatentDiffusion):
     """controlnet/cldm/cldm.py:816-849.  Several control models (BASELINE configs 4/5) are an extension: their
     residual lists are summed; cond['c_concat'] then carries one hint per control model."""
 
-    def __init__(self, unet_config=None, n_controlnets=1, only_mid_control=False, control_key='hint', **kw):
+    def __init__(self, unet_config=None, n_controlnets=1, only_mid_control=False, control_key='hint',
+                 control_stage_config=None, **kw):
         kw.setdefault('use_adapter', False)       # ControlledUnetModel is the plain SD UNet (cldm.py:26)
         kw.setdefault('image_size', 64)
+        self._check_control_stage(unet_config, control_stage_config)
         super().__init__(unet_config=unet_config, n_controlnets=n_controlnets, **kw)
         self.control_key = control_key
         self.only_mid_control = only_mid_control
         self.n_controlnets = n_controlnets
         self.control_scales = [1.0] * 13
+
+    @staticmethod
+    def _check_control_stage(unet_config, control_stage_config):
+        """cldm_v15_canny.yaml:21-36: control_stage_config must describe the twin of the UNet's encoder"""
+        if control_stage_config is None:
+            return
+        ckind, ccfg, cflags = _cfg.unet_params(control_stage_config)
+        _, ucfg, _ = _cfg.unet_params(unet_config)
+        ucfg = dict(_k.SD_V1 if ucfg is None else ucfg)
+        diff = [k for k in ccfg if k != 'out_channels' and tuple(np.atleast_1d(ccfg[k])) != tuple(np.atleast_1d(ucfg[k]))]
+        if ckind not in (None, 'controlnet') or diff or cflags.get('hint_channels', 3) != 3:
+            raise NotImplementedError(f'control_stage_config must be a ControlNet matching unet_config (differs in {diff})')
+
+    @classmethod
+    def engine_args(cls, unet_config=None, n_controlnets=1, control_stage_config=None, **kw):
+        kw.setdefault('use_adapter', False)
+        cls._check_control_stage(unet_config, control_stage_config)
+        return super().engine_args(unet_config=unet_config, n_controlnets=n_controlnets, **kw)
 
     def _scales(self):
         sc = list(self.control_scales)

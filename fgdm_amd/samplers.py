@@ -85,8 +85,12 @@ class _SamplerBase:
         c_in = self._batched_cond(uc, c)
         if c_in is None:        # conditionings that cannot share one batch: two calls (ddim_hacked.py:190-191)
             return self.model.apply_model(x, t, c, **kwargs), self.model.apply_model(x, t, uc, **kwargs)
-        # cfg_pairs: rows b and b + B of this batch differ only in the context (lets the engine share the network prefix)
-        e_u, e_c = self.model.apply_model(x_in, t_in, c_in, cfg_pairs=True, **kwargs).chunk(2)
+        # cfg_pairs: rows b and b + B of this batch differ only in the context (lets the engine share the network prefix).
+        # The hint is understood by this repo's mirrors only: any other `model` (e.g. the reference's LatentDiffusion,
+        # which forwards **kwargs into UNetModel.forward) is called exactly as the reference calls it.
+        if getattr(self.model, 'engine', None) is not None:
+            kwargs = dict(kwargs, cfg_pairs=True)
+        e_u, e_c = self.model.apply_model(x_in, t_in, c_in, **kwargs).chunk(2)
         return e_c.contiguous(), e_u.contiguous()
 
     @staticmethod
@@ -552,8 +556,8 @@ class DPMSolverSampler:
             if scale == 1. or uc is None:
                 e = self.model.apply_model(xx, t_in, conditioning)
             else:
-                out = self.model.apply_model(torch.cat([xx] * 2), torch.cat([t_in] * 2), torch.cat([uc, conditioning]),
-                                             cfg_pairs=True)
+                kw = {'cfg_pairs': True} if getattr(self.model, 'engine', None) is not None else {}
+                out = self.model.apply_model(torch.cat([xx] * 2), torch.cat([t_in] * 2), torch.cat([uc, conditioning]), **kw)
                 e_u, e_c = out.chunk(2)
                 e = _k.cfg_combine(e_c.contiguous(), e_u.contiguous(), scale)
             a, sg = ns.marginal_alpha(t), ns.marginal_std(t)

@@ -59,7 +59,10 @@ typedef struct fgdm_config {
 #define FGDM_FLAG_CFG_PAIRS 8         /* the batch is cat([x]*2), cat([t]*2) of a classifier-free-guidance step (ddim.py:222-
                                        * 226; same pcond, and the cached hint covers B/2 rows): rows b and b + B/2 differ only
                                        * in the context, so the network up to its first cross-attention runs once on B/2 rows.
-                                       * Results are bit-identical to the call without the flag. */
+                                       * Results are bit-identical to the call without the flag.  The flag is the CALLER's
+                                       * assertion that the halves are equal: with it only rows [0, B/2) of x, t and pcond are
+                                       * read for that prefix (pcond must still hold B rows); the host mirrors verify pcond
+                                       * before setting it (fgdm_amd/models.py). */
 
 int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out);
 void fgdm_destroy(fgdm_engine* e);
@@ -132,6 +135,19 @@ int fgdm_uint8_to_hint(const uint8_t* src, int B, int H, int W, int C, float* hi
 int fgdm_controlnet(fgdm_engine* e, int cn, const float* x, const int64_t* t, const float* ctx, int B, int H, int W,
                     float* out, int64_t out_capacity_floats, void* stream);
 
+/* One block of the loaded graph, addressed by its state-dict prefix -- the parity-test entry for the reference's block-level
+ * modules: a TimestepEmbedSequential ("model.diffusion_model.input_blocks.4.", "...middle_block.", "...output_blocks.0.",
+ * "control_model.input_blocks.1."; openaimodel.py:75-90) made of ResBlock (openaimodel.py:275-301), SpatialTransformer
+ * (ldm/modules/attention.py:275-292), Downsample / Upsample (openaimodel.py:114-180), or the FG-DM Adapter
+ * ("model.diffusion_model.adapter."; ldm/modules/encoders/adapter.py:334-346).
+ * x fp32 NCHW [B,C,H,W]; x_skip: for decoder blocks the second half of th.cat([h, hs.pop()], 1) (openaimodel.py:869) fp32 NCHW
+ * [B,Cs,H,W], else NULL; emb fp32 [B, 4*model_channels]: the `emb` the reference hands to the block (NULL if it has no
+ * ResBlock); ctx fp32 [B,77,context_dim] (NULL if it has no SpatialTransformer).  out: fp32 NCHW (Adapter: its four
+ * feature maps back to back); *out_numel = floats written. */
+int fgdm_run_block(fgdm_engine* e, const char* prefix, const float* x, int C, const float* x_skip, int Cs, const float* emb,
+                   const float* ctx, int B, int H, int W, float* out, int64_t out_capacity_floats, int64_t* out_numel,
+                   void* stream);
+
 /* One fused sampler update on fp32 tensors of n elements.
  * fgdm_ddim_step: p_sample_ddim's CFG combine + x_prev/pred_x0 (ldm/models/diffusion/ddim.py:243,254-268;
  * controlnet/cldm/ddim_hacked.py:192,203-231).  e_uncond NULL = no CFG; noise NULL = sigma term skipped;
@@ -183,6 +199,8 @@ int fgdm_op_linear(const void* x, const float* w, const float* bias, const void*
 int fgdm_debug_force_igemm_cfg(int cfg);
 int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample, int act,
                      int use_resid, int cfg, int iters, float* avg_ms);
+/* ... and one GroupNorm32(+SiLU) (kind 0, optional virtual concat C1) or LayerNorm (kind 1) shape. */
+int fgdm_bench_norm(int kind, int B, int HW, int C0, int C1, int silu, int iters, float* avg_ms);
 int fgdm_op_groupnorm(const void* x0, int C0, const void* x1, int C1, int B, int HW, const float* gamma,
                       const float* beta, float eps, int silu, void* out, void* stream);
 int fgdm_op_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps,

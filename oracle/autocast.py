@@ -42,6 +42,7 @@ _LOWER = {
     F.conv1d, F.conv2d, F.conv3d, F.conv_transpose2d, F.linear, torch._C._nn.linear,
     torch.matmul, T.matmul, T.__matmul__, torch.bmm, T.bmm, torch.mm, T.mm, torch.mv, T.mv,
     torch.addmm, T.addmm, torch.baddbmm, T.baddbmm, torch.addbmm, torch.einsum, torch.prelu, F.prelu,
+    F.scaled_dot_product_attention,
 }
 _FP32 = {
     F.group_norm, torch.group_norm, F.layer_norm, torch.layer_norm, torch.native_layer_norm,

@@ -22,6 +22,8 @@ TABLE = {
     'ops/attn160_x': ('attn_self160.x', (1, 64, 1280)),
     'ops/ff_x': ('ff.x', (2, 64, 320)),
     'ops/st_x': ('st.x', (2, 640, 8, 8)),
+    'ops/st320_x': ('st320.x', (2, 320, 16, 16)),
+    'ops/st1280_x': ('st1280.x', (2, 1280, 8, 8)),
     'ops/arb_x': ('arb.x', (2, 320, 16, 16)),
     'ops/adapter_x': ('adapter.x', (2, 4, 16, 16)),
     'unet/ctx': ('unet.ctx', (2, 77, 768)),
@@ -36,6 +38,8 @@ TABLE = {
     'samp/uc': ('samp.uc', (2, 77, 768)),
     'samp/mask': ('samp.mask', (2, 1, 8, 8)),
     'samp/x0': ('samp.x0', (2, 4, 8, 8)),
+    'samp/ac': ('samp.ac', (2, 77, 768)),
+    'samp/noise': ('samp.noise', (2, 4, 8, 8)),
     'sunet/x_T': ('sunet.xT', (2, 4, 16, 16)),
     'sunet/c': ('sunet.c', (2, 77, 768)),
     'sunet/uc': ('sunet.uc', (2, 77, 768)),

@@ -29,7 +29,9 @@ def _worker(rank, world, port, q):
         # only rank 0 can produce the weights; other ranks would produce garbage if asked
         make = (lambda k, s: synth.make_tensor(k, s)) if rank == 0 else (lambda k, s: np.full(s, np.nan, np.float32))
         sd, _ = fd.broadcast_weights(shapes, make, rank, world, 'cpu')
-        ok_w = all(np.array_equal(sd[k].numpy(), synth.make_tensor(k, s)) for k, s in shapes.items())
+        # >= 2-D weights travel as fp16 (what the engine stores), 1-D tensors as fp32: rank 0's bytes, exactly
+        ok_w = all(torch.equal(sd[k], torch.from_numpy(synth.make_tensor(k, s)).to(sd[k].dtype)) for k, s in shapes.items())
+        ok_w = ok_w and sd['a.weight'].dtype == torch.float16 and sd['a.bias'].dtype == torch.float32
         # global batch generated identically everywhere, then sliced
         N = 4
         x_T = torch.from_numpy(synth.latents(N, 8, 8, seed=42))

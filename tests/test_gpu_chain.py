@@ -45,7 +45,7 @@ def test_two_stage_chain_vs_oracle():
     a.engine.close()
     # ---------------- stage B on the engine, through the initialize_cn.process mirror
     from fgdm_amd import engine as eng
-    shapes_b = eng.param_shapes(eng.make_config(initialize_cn.CLDM_V15, n_controlnets=1, vae=True))
+    shapes_b = eng.param_shapes(eng.make_config(initialize_cn.CLDM_V15, n_controlnets=1, vae=True, clip=True))
     sd_b = {k: synth.make_tensor(k, s) for k, s in shapes_b.items()}
     model, sampler = initialize_cn.initialize_controlnet('seg', state_dict=sd_b)
     model.cond_stage_model = lambda prompts: _ctx(prompts, 200).cuda()
@@ -60,11 +60,16 @@ def test_two_stage_chain_vs_oracle():
     sched = schedule.register_schedule()
     pa = {k: torch.from_numpy(v) for k, v in sd_a.items()}
     fn_a = lambda x, t, cc: onn.unet_forward(pa, cfg, x, t, cc, prefix='model.diffusion_model.', use_adapter=True)
+    from common import check_net
+    from oracle import precision
     with torch.no_grad():
         z_ref, _ = osamp.ddim_sample(fn_a, sched, S, xT_a.shape, c.cpu(), xT_a, scale=7.5, uc=uc.cpu())
         img_ref = ovae.decode_first_stage(pa, z_ref)
-    assert report('chain stage A latent (2 DDIM steps, adapter, CFG 7.5) vs oracle', relerr(z_a.cpu(), z_ref), 1e-2) < 1e-2
-    assert report('chain stage A decoded 256x256 image vs oracle', relerr(img_a.cpu(), img_ref), 1e-2) < 1e-2
+        with precision.mode('autocast'):     # the reference's own GPU numerics on the same chain: the floor
+            z_ac, _ = osamp.ddim_sample(fn_a, sched, S, xT_a.shape, c.cpu(), xT_a, scale=7.5, uc=uc.cpu())
+            img_ac = ovae.decode_first_stage(pa, z_ac)
+    check_net('chain stage A latent (2 DDIM steps, adapter, CFG 7.5)', z_a.cpu(), z_ref, z_ac.float())
+    check_net('chain stage A decoded 256x256 image', img_a.cpu(), img_ref, img_ac.float())
     u8_ref = ob.image_to_uint8(img_ref.numpy(), 0)
     big_ref = ob.resize_linear_u8(u8_ref, 512, 512)
     d = np.abs(big_u8.cpu().numpy().astype(np.int32) - big_ref.astype(np.int32))

@@ -220,3 +220,24 @@ def test_batched_conditioning_is_built_once_per_sample(stubs):
     smp.sample(4, 2, (4, 8, 8), {'c_concat': [hint], 'c_crossattn': [c]}, verbose=False, x_T=x_T,
                unconditional_guidance_scale=9.0, unconditional_conditioning={'c_concat': [hint], 'c_crossattn': [uc]})
     assert len(seen) == 4 and all(s is seen[0] for s in seen)
+
+
+def test_sampler_branches_vs_reference(stubs):
+    """composable_diffusion, augmented_conditoning, score_corrector, timesteps=, decode, use_original_steps,
+    stochastic_encode, ucg_schedule: written in round 1, first exercised here."""
+    import sampler_branches
+    from test_oracle_golden import analytic_eps as ae
+
+    def make_model(hint=None):
+        if hint is None:
+            return AnalyticLDM()
+
+        class M(AnalyticLDM):
+            def apply_model(self, x, t, cc, **kw):
+                self.calls += 1
+                if cc['c_crossattn'][0].shape[0] == 2 * hint.shape[0]:      # batched CFG: the hint serves both halves
+                    cc = {'c_concat': [torch.cat([hint, hint])], 'c_crossattn': cc['c_crossattn']}
+                return ae(x, t, cc)
+        return M()
+    err = sampler_branches.run(make_model, 'cpu', STOL)
+    print(err)

@@ -283,6 +283,12 @@ def g_ops():
             b.checkpoint = False
         load_synth(m, 'st.')
         arrs['st_y'] = m(gi.get('ops/st_x'), context=ctx)
+        for tag, (ch, dh) in dict(st320=(320, 40), st1280=(1280, 160)).items():     # head dims 40 and 160
+            m = SpatialTransformer(ch, 8, dh, depth=1, context_dim=768).eval()
+            for b in m.transformer_blocks:
+                b.checkpoint = False
+            load_synth(m, tag + '.')
+            arrs[tag + '_y'] = m(gi.get(f'ops/{tag}_x'), context=ctx)
         # adapter pieces
         x = gi.get('ops/arb_x')
         m = ResnetBlock(320, 640, down=True, ksize=1, sk=True, use_conv=False).eval()
@@ -545,6 +551,80 @@ def g_samplers2():
     save('samplers2', **arrs)
 
 
+class Corrector:
+    """a score_corrector in the sense of ddim.py:245-247: any object with modify_score(model, e_t, x, t, c, **kwargs)"""
+
+    def modify_score(self, model, e_t, x, t, c, gain=1.0):
+        return e_t + gain * 0.1 * torch.tanh(x) * (t.float() / 1000.0).reshape(-1, 1, 1, 1)
+
+
+def g_samplers3():
+    """Sampler branches that exist in the reference but that no script exercises, with the analytic model:
+    composable_diffusion (ddim.py:204-212), augmented_conditoning + ac (:213-220), score_corrector (:245-247),
+    ddim_sampling(timesteps=) truncation (:131-134), use_original_steps / decode (:395-412, :249-252),
+    stochastic_encode (:379-393), ControlNet sampler ucg_schedule (ddim_hacked.py:159-161)."""
+    import contextlib
+    import io
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from controlnet.cldm.ddim_hacked import DDIMSampler as CNSampler
+    arrs = {}
+    shape = (4, 8, 8)
+    x_T, c, uc = gi.get('samp/x_T'), gi.get('samp/c'), gi.get('samp/uc')
+    sink = io.StringIO()
+    with torch.no_grad(), contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+        # composable diffusion: ONE latent, two prompts and one unconditional context
+        fm = FakeModel(analytic_eps)
+        out, _ = _cpu_sampler(DDIMSampler)(fm).sample(10, 1, shape, conditioning=c, x_T=x_T[:1], eta=0.0, verbose=False,
+                                                     unconditional_guidance_scale=7.5, unconditional_conditioning=uc[:1],
+                                                     composable_diffusion=2)
+        arrs['compose'] = out
+        arrs['compose_calls'] = np.asarray([fm.calls])
+        # augmented conditioning: third context `ac`, two nested guidance combinations
+        fm = FakeModel(analytic_eps)
+        ac = gi.get('samp/ac')
+        out, _ = _cpu_sampler(DDIMSampler)(fm).sample(10, 2, shape, conditioning=c, x_T=x_T, eta=0.0, verbose=False,
+                                                     unconditional_guidance_scale=3.0, unconditional_conditioning=uc,
+                                                     augmented_conditoning=True, ac=ac)
+        arrs['augmented'] = out
+        arrs['augmented_calls'] = np.asarray([fm.calls])
+        fm = FakeModel(analytic_eps)
+        out, _ = _cpu_sampler(DDIMSampler)(fm).sample(10, 2, shape, conditioning=c, x_T=x_T, eta=0.0, verbose=False,
+                                                     unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                                                     score_corrector=Corrector(), corrector_kwargs={'gain': 0.5})
+        arrs['corrector'] = out
+        # ddim_sampling(timesteps=10) on a 20-step schedule: the first 9 ddim timesteps
+        fm = FakeModel(analytic_eps)
+        smp = _cpu_sampler(DDIMSampler)(fm)
+        smp.make_schedule(20, ddim_eta=0.0, verbose=False)
+        out, inter = smp.ddim_sampling(c, (2,) + shape, x_T=x_T, timesteps=10, unconditional_guidance_scale=7.5,
+                                       unconditional_conditioning=uc, log_every_t=1)
+        arrs['truncated'] = out
+        arrs['truncated_n'] = np.asarray([fm.calls])
+        # decode from ddim index 12, and from step 15 of the ORIGINAL 1000-step schedule (the reference reads the sigmas for
+        # that from self.model, ddim.py:252, so the model has to carry them)
+        x_lat = gi.get('samp/x0')
+        fm = FakeModel(analytic_eps)
+        smp = _cpu_sampler(DDIMSampler)(fm)
+        smp.make_schedule(20, ddim_eta=0.0, verbose=False)
+        arrs['decode_ddim12'] = smp.decode(x_lat, c, 12, unconditional_guidance_scale=5.0, unconditional_conditioning=uc)
+        fm.ddim_sigmas_for_original_num_steps = smp.ddim_sigmas_for_original_num_steps
+        arrs['decode_orig15'] = smp.decode(x_lat, c, 15, unconditional_guidance_scale=5.0, unconditional_conditioning=uc,
+                                           use_original_steps=True)
+        noise = gi.get('samp/noise')
+        arrs['stoch_ddim7'] = smp.stochastic_encode(x_lat, torch.tensor([7, 7]), noise=noise)
+        arrs['stoch_orig300'] = smp.stochastic_encode(x_lat, torch.tensor([300, 300]), use_original_steps=True, noise=noise)
+        # ControlNet sampler with a guidance-scale schedule
+        hint = gi.hint(2, 64, 48)
+        fm = FakeModel(analytic_eps)
+        ucg = [1.0 + 0.8 * i for i in range(10)]
+        out, _ = _cpu_sampler(CNSampler)(fm).sample(10, 2, shape, {'c_concat': [hint], 'c_crossattn': [c]}, verbose=False, eta=0.0,
+                                                   x_T=x_T, unconditional_guidance_scale=9.0, ucg_schedule=ucg,
+                                                   unconditional_conditioning={'c_concat': [hint], 'c_crossattn': [uc]})
+        arrs['cn_ucg'] = out
+        arrs['cn_ucg_schedule'] = np.asarray(ucg)
+    save('samplers3', **arrs)
+
+
 def g_sampler_unet():
     """End-to-end compounding: reference DDIMSampler driving the reference reduced UNet (SMALL_CFG) at 16x16."""
     import contextlib
@@ -566,14 +646,77 @@ def g_sampler_unet():
     save('sampler_unet', **arrs)
 
 
+def g_full_size():
+    """G7: the metric's own workload at full size -- SD-v1.5-width ControlledUnetModel + ControlNet, latent 64x64,
+    hint 512x512 -- through the reference's modules wired as ControlLDM.apply_model does (cldm.py:836-849):
+      * one classifier-free-guidance pair (same x and hint, uncond / cond context) at t = 981 and t = 21;
+      * a complete 50-step eta = 0 DDIM sampling, CFG 9.0, with the reference's ControlNet sampler (ddim_hacked.py:55-231):
+        the latent after steps 1, 2, 5, 10, 20, 30, 40, 50 and (sum, L2 norm) of every step's latent and pred_x0."""
+    import contextlib
+    import io
+    import time
+    from controlnet.cldm.cldm import ControlNet, ControlledUnetModel
+    from controlnet.cldm.ddim_hacked import DDIMSampler as CNSampler
+    cn = ControlNet(**ref_cfg(gi.SD_CFG, hint_channels=3)).eval()
+    load_synth(cn, 'control_model.')
+    cu = ControlledUnetModel(**ref_cfg(gi.SD_CFG)).eval()
+    load_synth(cu, 'model.diffusion_model.')
+    scales = [1.0] * 13
+
+    def apply_model(x, t, cond):
+        ctx = torch.cat(cond['c_crossattn'], 1)
+        control = cn(x=x, hint=torch.cat(cond['c_concat'], 1), timesteps=t, context=ctx)
+        control = [c * s for c, s in zip(control, scales)]
+        return cu(x=x, timesteps=t, context=ctx, control=control, only_mid_control=False)
+    x = torch.from_numpy(synth.latents(1, 64, 64, seed=42))
+    c = torch.from_numpy(synth.context(1, seed=43))
+    uc = torch.from_numpy(synth.context(1, seed=44))
+    hint = torch.from_numpy(synth.hint(1, 512, seed=45))
+    arrs = {}
+    t0 = time.time()
+    with torch.no_grad():
+        for tv in (981, 21):
+            t = torch.full((2,), tv, dtype=torch.long)
+            arrs[f'eps_pair_t{tv}'] = apply_model(torch.cat([x, x]), t, {'c_concat': [torch.cat([hint, hint])],
+                                                                       'c_crossattn': [torch.cat([uc, c])]})
+        print(f'   CFG pairs done, {time.time() - t0:.0f} s', flush=True)
+        fm = FakeModel(lambda xx, tt, cc: apply_model(xx, tt, cc))
+        smp = _cpu_sampler(CNSampler)(fm)
+        keep = {1, 2, 5, 10, 20, 30, 40, 50}
+        sums = []
+
+        def img_cb(pred_x0, i):
+            pass
+        sink = io.StringIO()
+        traj = {}
+        # the sampler reports pred_x0 through img_callback and x through the intermediates (log_every_t = 1)
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            out, inter = smp.sample(50, 1, (4, 64, 64), {'c_concat': [hint], 'c_crossattn': [c]}, verbose=False, eta=0.0,
+                                    x_T=x, unconditional_guidance_scale=9.0, log_every_t=1,
+                                    unconditional_conditioning={'c_concat': [hint], 'c_crossattn': [uc]})
+        xs = inter['x_inter'][1:]           # [0] is x_T
+        ps = inter['pred_x0'][1:]
+        assert len(xs) == 50, len(xs)
+        for i, (xi, pi) in enumerate(zip(xs, ps)):
+            xi, pi = xi.float(), pi.float()
+            sums.append([float(xi.double().sum()), float(xi.double().norm()), float(pi.double().sum()), float(pi.double().norm())])
+            if i + 1 in keep:
+                arrs[f'x_step{i + 1}'] = xi
+        arrs['traj_sums'] = np.asarray(sums)
+        arrs['out'] = out.float()
+        arrs['calls'] = np.asarray([fm.calls])
+    print(f'   50-step trajectory done, {time.time() - t0:.0f} s', flush=True)
+    save('full_size', **arrs)
+
+
 ALL = dict(schedule=g_schedule, ddpm_schedule=g_ddpm_schedule, param_keys=g_param_keys, ops=g_ops,
            unet_full=g_unet_full, controlnet_full=g_controlnet_full, small_nets=g_small_nets,
-           samplers=g_samplers, samplers2=g_samplers2, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip, adapt_unet=g_adapt_unet)
+           samplers=g_samplers, samplers2=g_samplers2, samplers3=g_samplers3, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip, adapt_unet=g_adapt_unet, full_size=g_full_size)
 
 
 # generators that are ALSO run with the reference's modules under the emulated torch.autocast("cuda") policy
 # (scripts/txt2img_fgdm_inference.py:212-217 wraps the whole sampling loop in it) -> tests/golden/<name>_ac.npz
-AC = ('ops', 'unet_full', 'controlnet_full', 'small_nets', 'sampler_unet', 'adapt_unet')
+AC = ('ops', 'unet_full', 'controlnet_full', 'small_nets', 'sampler_unet', 'adapt_unet', 'vae', 'clip', 'full_size')
 
 
 def main():
