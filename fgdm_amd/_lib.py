@@ -74,7 +74,9 @@ SIGNATURES = {
     'fgdm_op_linear': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     'fgdm_debug_force_igemm_cfg': (_i, [_i]),
     'fgdm_bench_igemm': (_i, [_i] * 13 + [C.POINTER(_f)]),
+    'fgdm_op_linear_ln_linear': (_i, [_p] * 8 + [_i] * 5 + [_p, _p, C.POINTER(_i), _p]),
     'fgdm_bench_norm': (_i, [_i] * 7 + [C.POINTER(_f)]),
+    'fgdm_bench_attention': (_i, [_i] * 6 + [C.POINTER(_f)]),
     'fgdm_op_groupnorm': (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _f, _i, _p, _p]),
     'fgdm_op_layernorm': (_i, [_p, _i, _i, _p, _p, _f, _p, _p]),
     'fgdm_op_attention': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -27,6 +27,8 @@
 // score registers, 128 VGPRs, 4 waves per SIMD, no spill) is not faster either (549 vs 557-606 TF/s): v_exp_f32 issues
 // at a quarter of the VALU rate, the 33 exp2 per 64 keys are ~530 of the ~1000 cycles a wave-tile takes on its SIMD.
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 #define ATT_THR 8.0f
 
@@ -107,66 +109,100 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
     const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
 
-    // register prefetch of one K / Vt tile
+    // register prefetch of one K / Vt tile.  Everything per-thread about the copy is loop-invariant and computed here, the
+    // tile base is wave-uniform (scalar), chunk validity is wave-uniform too (64 * DC and D * 8 are multiples of 64), and
+    // the K loop below is unrolled over the two LDS buffers so that their offsets are immediates: the loop carries no
+    // address arithmetic or per-lane predicates (PMC, round 2: 114 VALU instructions per 64-key tile of which 64 were the
+    // softmax itself; the kernel is vector-issue bound, so the other 50 cost as much as a fifth of the tile).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int k_goff[KCH], k_loff[KCH], k_key[KCH], v_goff[VCH], v_loff[VCH];
+#pragma unroll
+    for (int u = 0; u < KCH; ++u) {
+        const int i = tid + u * 256, key = i / DC, c = i - key * DC;
+        k_key[u] = key; k_goff[u] = key * ldk + c * 8; k_loff[u] = key * KS + c * 16;
+    }
+#pragma unroll
+    for (int u = 0; u < VCH; ++u) {
+        const int i = tid + u * 256, r = i >> 3, c = i & 7;
+        v_goff[u] = r * ldvt + c * 8; v_loff[u] = r * VS + c * 16;
+    }
     h8 kreg[KCH], vreg[VCH];
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&](int k0, bool ragged) {
+        const half_t* kb = Kb + (size_t)k0 * ldk;
+        const half_t* vb = Vb + k0;
 #pragma unroll
-        for (int u = 0; u < KCH; ++u) {
-            const int i = tid + u * 256;
-            const int key = i / DC, c = i - key * DC;
-            kreg[u] = (h8)(half_t)0;
-            if (i < 64 * DC && k0 + key < Tk) kreg[u] = *(const h8*)(Kb + (size_t)(k0 + key) * ldk + c * 8);
-        }
+        for (int u = 0; u < KCH; ++u)
+            if ((u * 4 + wave_u) * 64 < 64 * DC) {
+                int off = k_goff[u];
+                // rows past Tk: re-read the last valid row (their scores are masked to -inf below; never out of bounds)
+                if (ragged) off += (min(k_key[u], Tk - 1 - k0) - k_key[u]) * ldk;
+                kreg[u] = *(const h8*)(kb + off);
+            }
 #pragma unroll
-        for (int u = 0; u < VCH; ++u) {
-            const int i = tid + u * 256;
-            if (i < D * 8) vreg[u] = *(const h8*)(Vb + (size_t)(i >> 3) * ldvt + k0 + (i & 7) * 8);
-        }
+        for (int u = 0; u < VCH; ++u)
+            if ((u * 4 + wave_u) * 64 < D * 8) vreg[u] = *(const h8*)(vb + v_goff[u]);     // Vt rows are padded to 64 keys
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
         char* Ksb = smem + buf * (KBYTES + VBYTES);
         char* Vsb = Ksb + KBYTES;
 #pragma unroll
-        for (int u = 0; u < KCH; ++u) {
-            const int i = tid + u * 256;
-            const int key = i / DC, c = i - key * DC;
-            if (i < 64 * DC) *(h8*)(Ksb + key * KS + c * 16) = kreg[u];
-        }
+        for (int u = 0; u < KCH; ++u)
+            if ((u * 4 + wave_u) * 64 < 64 * DC) *(h8*)(Ksb + k_loff[u]) = kreg[u];
 #pragma unroll
-        for (int u = 0; u < VCH; ++u) {
-            const int i = tid + u * 256;
-            if (i < D * 8) {
-                const int r = i >> 3, c = i & 7;
+        for (int u = 0; u < VCH; ++u)
+            if ((u * 4 + wave_u) * 64 < D * 8) {
                 const h8 v = vreg[u];
                 h4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-                *(h4*)(Vsb + r * VS + c * 16) = lo;
-                *(h4*)(Vsb + r * VS + c * 16 + 8) = hi;
+                *(h4*)(Vsb + v_loff[u]) = lo;
+                *(h4*)(Vsb + v_loff[u] + 8) = hi;
             }
-        }
     };
+    // fragment addresses inside a tile (bytes): loop-invariant too
+    const int kfrag = lq * KS + 8 * lh * 2, vfrag = lq * VS + 4 * lh * 2;
 
-    load_tile(0);
-    store_tile(0);
-    int cur = 0;
-    for (int k0 = 0; k0 < Tk; k0 += 64) {
+    load_tile(0, Tk < 64);
+    store_tile(std::integral_constant<int, 0>{});
+    auto tile = [&](int k0, auto curc) {
+        constexpr int cur = decltype(curc)::value;
         const bool more = k0 + 64 < Tk;
-        if (more) load_tile(k0 + 64);      // global loads fly while this tile is computed
+        if (more) load_tile(k0 + 64, k0 + 128 > Tk);      // global loads fly while this tile is computed
         __syncthreads();                   // buffer `cur` is complete; buffer cur^1 is no longer read by anyone
         const char* Ks = smem + cur * (KBYTES + VBYTES);
         const char* Vs = Ks + KBYTES;
 
-        // ---- S^T = K Q^T for two 32-key sub-tiles
+        // ---- S^T = K Q^T for two 32-key sub-tiles.  ALL K fragments of the tile are requested first, then the MFMAs run
+        // behind counted lgkmcnt waits: a read-wait-MFMA chain per fragment left the wave parked on LDS latency ~13 times per
+        // tile (the ISA of the previous version: ds_read_b128, s_waitcnt lgkmcnt(0), v_mfma ... six times over).
+        h8 kf[2][NKS];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) kf[sub][s] = *(const h8*)(Ks + kfrag + sub * 32 * KS + 16 * s * 2);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 sacc[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                const h8 kf = *(const h8*)(Ks + (sub * 32 + lq) * KS + (16 * s + 8 * lh) * 2);
-                sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[sub], 0, 0, 0);
-            }
+            for (int s = 0; s < NKS; ++s) sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sub][s], qf[s], sacc[sub], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the V^T fragments of the whole tile are requested NOW (into the registers the K fragments just left): they land
+        // while the softmax below keeps the VALU busy, so the PV MFMAs start without an LDS round trip
+        h4 v0f[2][2][DT], v1f[2][2][DT];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const char* vp = Vs + vfrag + t * 32 * VS + (sub * 32 + 16 * s) * 2;
+                    v0f[sub][s][t] = *(const h4*)vp;
+                    v1f[sub][s][t] = *(const h4*)(vp + 16);
+                }
+        __builtin_amdgcn_sched_barrier(0);
         if (k0 + 64 > Tk) {   // ragged last tile: keys >= Tk get -inf
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -242,16 +278,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
                 for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[sub][8 * s + j];
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
-                    const char* vp = Vs + (t * 32 + lq) * VS + (sub * 32 + 16 * s + 4 * lh) * 2;
-                    const h4 v0 = *(const h4*)vp;
-                    const h4 v1 = *(const h4*)(vp + 16);
+                    const h4 v0 = v0f[sub][s][t], v1 = v1f[sub][s][t];
                     const h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[t], 0, 0, 0);
                 }
             }
         }
-        if (more) store_tile(cur ^ 1);     // safe: everyone passed this iteration's barrier after reading cur^1
-        cur ^= 1;
+        if (more) store_tile(std::integral_constant<int, cur ^ 1>{});     // safe: everyone passed this iteration's barrier after reading cur^1
+    };
+    for (int k0 = 0; k0 < Tk; k0 += 128) {
+        tile(k0, std::integral_constant<int, 0>{});
+        if (k0 + 64 < Tk) tile(k0 + 64, std::integral_constant<int, 1>{});
     }
 
     float l_tot;
@@ -283,6 +320,302 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     }
 }
 
+
+// =====================================================================================================================
+// Ping-pong variant for long self-attention (round 2).  PMC on the kernel above (T = Tk = 4096, d = 40): per SIMD the matrix
+// pipe is busy 40 % of the time and the vector ALU 52 % -- and the two hardly ever at the same moment: three free-running
+// waves per SIMD drift into the same phase, all in their softmax, then all in their MFMAs.  Here a workgroup has EIGHT waves,
+// two per SIMD: group A (waves 0-3) and group B (waves 4-7) own 128 queries each and run the SAME program one barrier apart,
+// so that on every SIMD one wave is in its MFMA slot {P V of tile k, Q K^T of tile k+1} while its partner is in its VALU slot
+// {softmax of tile k, LDS writes of the next K / V^T tile}; two raw s_barriers per tile keep them there.
+//   slot:      0        1        2        3        4   ...
+//   group A:  QK(0)    X(0)     Y(0)     X(1)     Y(1)          X(k) = softmax(k) + stage tile, Y(k) = PV(k) + QK(k+1)
+//   group B:   -       QK(0)    X(0)     Y(0)     X(1)
+// K / V^T live in LDS as PAIRS p(j) = (K tile j+1, V^T tile j), double-buffered (buffer j & 1; K tile 0 is "p(-1)"): p(j) is
+// read in slots 2j+2 (A) and 2j+3 (B), each wave writes its share of it in its own X phase -- A in X(j) (slot 2j+1), B in
+// X(j-1) (slot 2j) -- which is after the last read of p(j-2) (slot 2j-1) and before the first read of p(j).  Every wave
+// executes the same number of barriers (B one extra at the start, A one extra at the end).
+template <int D>
+__global__ __launch_bounds__(512) void attn_pp_kernel(const half_t* __restrict__ Q, int ldq,
+                                                      const half_t* __restrict__ K, int ldk,
+                                                      const half_t* __restrict__ Vt, int ldvt,
+                                                      half_t* __restrict__ O, int ldo,
+                                                      int H, int T, int Tk, float sl2e) {
+    constexpr int DP = (D + 15) / 16 * 16, NKS = DP / 16, DT = (D + 31) / 32;
+    constexpr bool ONES = (DT * 32 > D);
+    constexpr bool FOLD = (DP > D) && (D % 8 == 0);
+    constexpr int PS = D / 16, PH = (D % 16) / 8;
+    constexpr int KS = DP * 2 + 16, VS = 64 * 2 + 8, DC = D / 8;
+    constexpr int NCH = 64 * DC;                    // 16-byte chunks of a K tile = of a V^T tile (D * 8)
+    constexpr int CH = (NCH + 511) / 512;           // chunks per thread per tile
+    constexpr int KBYTES = 64 * KS, VBYTES = DT * 32 * VS, PAIR = KBYTES + VBYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * PAIR];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                      // 0 = A, 1 = B
+    const int lq = lane & 31, lh = lane >> 5;
+    const int nqb = (T + 255) / 256;
+    const int nb = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qd = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
+    }
+    const int qblk = logical % nqb, bh = logical / nqb;
+    const int b = bh / H, head = bh - b * H;
+    const int q = qblk * 256 + wave * 32 + lq;
+    const int nt = (Tk + 63) / 64;
+
+    // pad regions of both buffers, written once (visible after the prologue barrier)
+    for (int buf = 0; buf < 2; ++buf) {
+        char* Ksb = smem + buf * PAIR;
+        char* Vsb = Ksb + KBYTES;
+        if constexpr (DP > D) {
+            for (int i = tid; i < 64 * (DP - D) / 8; i += 512) {
+                const int key = i / ((DP - D) / 8), c = i % ((DP - D) / 8);
+                h8 pad = (h8)(half_t)0;
+                if (FOLD && c == 0) pad[0] = (half_t)1;
+                *(h8*)(Ksb + key * KS + (D + c * 8) * 2) = pad;
+            }
+        }
+        for (int i = tid; i < (DT * 32 - D) * 16; i += 512) {
+            const int r = D + i / 16, c = i % 16;
+            *(h4*)(Vsb + r * VS + c * 8) = (r == D) ? (h4)(half_t)1 : (h4)(half_t)0;
+        }
+    }
+
+    h8 qf[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const int c = 16 * s + 8 * lh;
+        qf[s] = (h8)(half_t)0;
+        if (c < D && q < T) qf[s] = *(const h8*)(Q + ((size_t)b * T + q) * ldq + head * D + c);
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = (half_t)((float)qf[s][j] * sl2e);
+        }
+    }
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = FOLD ? 0.f : -INFINITY, l_run = 0.f;
+
+    const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
+    const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
+
+    // per-thread, loop-invariant parts of the tile copy; chunk validity is wave-uniform (NCH is a multiple of 64)
+    int k_goff[CH], k_loff[CH], k_key[CH], v_goff[CH], v_loff[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        const int i = tid + u * 512;
+        const int key = i / DC, c = i - key * DC;
+        k_key[u] = key; k_goff[u] = key * ldk + c * 8; k_loff[u] = key * KS + c * 16;
+        const int r = i >> 3, cv = i & 7;
+        v_goff[u] = r * ldvt + cv * 8; v_loff[u] = r * VS + cv * 16;
+    }
+    h8 kreg[CH], vreg[CH];
+    // K tile kt and V^T tile vtile -> registers (either may be absent: kt >= nt / vtile < 0)
+    auto load_pair = [&](int kt, int vtile) {
+        if (kt < nt) {
+            const int k0 = kt * 64;
+            const half_t* kb = Kb + (size_t)k0 * ldk;
+            const bool ragged = k0 + 64 > Tk;
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if ((u * 8 + wave) * 64 < NCH) {
+                    int off = k_goff[u];
+                    if (ragged) off += (min(k_key[u], Tk - 1 - k0) - k_key[u]) * ldk;
+                    kreg[u] = *(const h8*)(kb + off);
+                }
+        }
+        if (vtile >= 0 && vtile < nt) {
+            const half_t* vb = Vb + vtile * 64;
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if ((u * 8 + wave) * 64 < NCH) vreg[u] = *(const h8*)(vb + v_goff[u]);
+        }
+    };
+    auto store_pair = [&](int kt, int vtile, int buf) {
+        char* Ksb = smem + buf * PAIR;
+        char* Vsb = Ksb + KBYTES;
+        if (kt < nt) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if ((u * 8 + wave) * 64 < NCH) *(h8*)(Ksb + k_loff[u]) = kreg[u];
+        }
+        if (vtile >= 0 && vtile < nt) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if ((u * 8 + wave) * 64 < NCH) {
+                    const h8 v = vreg[u];
+                    h4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+                    *(h4*)(Vsb + v_loff[u]) = lo;
+                    *(h4*)(Vsb + v_loff[u] + 8) = hi;
+                }
+        }
+    };
+    auto barrier = [&]() { __syncthreads(); };    // workgroup-scope fences + s_barrier: LDS traffic drained, global prefetches stay in flight
+    const int kfrag = lq * KS + 8 * lh * 2, vfrag = lq * VS + 4 * lh * 2;
+
+    f32x16 sacc[2];
+    h8 pf[2][2];                       // fp16 probabilities of the tile: the B operand of P V
+    auto qk = [&](int buf) {           // S^T = K Q^T of the K tile in `buf`
+        const char* Ks = smem + buf * PAIR;
+        h8 kf[2][NKS];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) kf[sub][s] = *(const h8*)(Ks + kfrag + sub * 32 * KS + 16 * s * 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sub][s], qf[s], sacc[sub], 0, 0, 0);
+        }
+    };
+    auto pv = [&](int buf) {           // O^T += V^T P^T with the V^T tile in `buf`
+        const char* Vs = smem + buf * PAIR + KBYTES;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const char* vp = Vs + vfrag + t * 32 * VS + (sub * 32 + 16 * s) * 2;
+                    const h4 v0 = *(const h4*)vp, v1 = *(const h4*)(vp + 16);
+                    const h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sub][s], oacc[t], 0, 0, 0);
+                }
+    };
+    auto softmax = [&](int k0, bool first) {      // sacc -> pf (online softmax in the log2 domain, deferred rescale)
+        if (k0 + 64 > Tk) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= Tk) sacc[sub][r] = -INFINITY;
+                }
+        }
+        float psum = 0.f;
+        if constexpr (FOLD) {
+            float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (first || !__all(mx <= ATT_THR)) {
+                const float m_new = first ? mx : m_run + fmaxf(mx, 0.f);
+                const float m_hat = (float)(half_t)m_new;
+                const float delta = m_run - m_hat;
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(delta);
+                m_run = m_hat;
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[sub][r] += delta;
+                if (lh == PH) qf[PS][0] = (half_t)(-m_hat);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[sub][r] = __builtin_amdgcn_exp2f(sacc[sub][r]);
+        } else {
+            float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2e;
+            if (!__all(mx - m_run <= ATT_THR)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[sub][r] * sl2e - m_run);
+                    sacc[sub][r] = p;
+                    if constexpr (!ONES) psum += p;
+                }
+        }
+        if constexpr (!ONES) l_run += psum;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[sub][s][j] = (half_t)sacc[sub][8 * s + j];
+    };
+
+    // ---- prologue: K tile 0 ("pair -1") into buffer 1; group B also writes its shares of pair 0 = (K tile 1, V^T tile 0)
+    load_pair(0, -1);
+    store_pair(0, -1, 1);
+    if (grp == 1) {
+        load_pair(1, 0);
+        store_pair(1, 0, 0);
+    }
+    load_pair(1 + grp, grp);           // the pair this wave writes in X(0): A pair 0, B pair 1
+    barrier();
+    if (grp == 1) barrier();           // group B runs one slot behind group A
+    qk(1);                             // Q K^T of tile 0
+    for (int k = 0; k < nt; ++k) {
+        barrier();
+        // ---- X(k): VALU slot
+        softmax(k * 64, k == 0);
+        {
+            const int j = k + grp;                         // pair written in this phase (pair j = K tile j+1, V^T tile j)
+            if (j < nt) store_pair(j + 1, j, j & 1);
+            if (j + 1 < nt) load_pair(j + 2, j + 1);       // ... and the one after it starts its trip from HBM / L2
+        }
+        barrier();
+        // ---- Y(k): matrix slot
+        pv(k & 1);
+        if (k + 1 < nt) qk(k & 1);                         // K tile k+1 travels in pair k
+    }
+    if (grp == 0) barrier();
+
+    float l_tot;
+    if constexpr (ONES) {
+        constexpr int rr = D % 32;
+        constexpr int reg = (rr & 3) + 4 * (rr >> 3);
+        constexpr int owner_half = (rr >> 2) & 1;
+        const float mine = oacc[D / 32][reg];
+        const float other = __shfl_xor(mine, 32);
+        l_tot = (lh == owner_half) ? mine : other;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.0f / l_tot;
+    if (q < T) {
+        half_t* op = O + ((size_t)b * T + q) * ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = t * 32 + 8 * g + 4 * lh;
+                if (dd < D) {
+                    h4 pk = {(half_t)(oacc[t][4 * g] * inv), (half_t)(oacc[t][4 * g + 1] * inv),
+                             (half_t)(oacc[t][4 * g + 2] * inv), (half_t)(oacc[t][4 * g + 3] * inv)};
+                    *(h4*)(op + dd) = pk;
+                }
+            }
+    }
+}
+
 int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* Vt, int ldvt, half_t* O,
                      int ldo, int B, int H, int T, int Tk, int d, int q_prescaled, hipStream_t s) {
     if (B <= 0 || H <= 0 || T <= 0 || Tk <= 0) return FGDM_ERR_ARG;
@@ -290,6 +623,14 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
     // q_prescaled: the to_q weights were packed with log2(e) d^-1/2 folded in (fgdm_finalize_weights), so Q arrives in the
     // log2 domain with ONE fp16 rounding; the kernels then multiply by exactly 1
     const float sl2e = q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)d);
+    // long self-attention: the eight-wave ping-pong kernel (256 queries per workgroup); FGDM_ATTN_PP=0 switches it off (A/B)
+    static const bool pp_on = !(getenv("FGDM_ATTN_PP") && atoi(getenv("FGDM_ATTN_PP")) == 0);
+    if (pp_on && T >= 256 && Tk >= 256 && (d == 40 || d == 80)) {
+        const dim3 grid2(((T + 255) / 256) * H * B), block2(512);
+        if (d == 40) hipLaunchKernelGGL(attn_pp_kernel<40>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        else hipLaunchKernelGGL(attn_pp_kernel<80>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+    }
     const dim3 grid(((T + 127) / 128) * H * B), block(256);
     switch (d) {
         case 40: hipLaunchKernelGGL(attn_kernel<40>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;

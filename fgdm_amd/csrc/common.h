@@ -46,11 +46,31 @@ struct IgemmArgs {
     float* ws;             //      [splitk][M][N] and igemm_splitk_reduce applies the epilogue (deterministic order)
     int debug;             // ablation switches for tools/bench_igemm.py only: 1 = skip global->LDS loads in the K loop,
                            // 2 = skip the MFMAs, 4 = skip the epilogue stores (results are then meaningless)
+    // ---- LayerNorm folded into a LINEAR GEMM (attention.py:234-240: attn(norm(x)), ff(norm(x))).  A is the RAW row x; the
+    // packed weights are W'[n][k] = fp16(gamma[k] W[n][k]), `bias` holds sum_k beta[k] W[n][k] + b[n], `ln_u` holds
+    // sum_k W'[n][k]; with (mean, rstd) of row m from the producer's partial sums the epilogue evaluates
+    //     rstd_m (acc_mn - mean_m u_n) + bias_n   ==   sum_k ((x_mk - mean_m) rstd_m gamma_k + beta_k) W_nk + b_n
+    // so no normalised copy of x is ever written or read.
+    const float* ln_stats; // [M][ln_slots][2] partial (sum, sum of squares) over column slices of row m, or null
+    const float* ln_u;     // [N] (packed order)
+    int ln_slots;
+    float ln_eps;          // (K = C0 is the length of the normalised vector)
+    // ---- ... and the producer side: emit those partial sums for the rows this GEMM writes (OUT_F16 only), computed from the
+    // stored fp16 values (after the residual add), one slot per 160-column slice, fixed order: stats_out[m][N / 160][2]
+    float* stats_out;
+    // ---- second destination: packed output columns >= split_n go to out2 (own kind / row stride, columns renumbered from 0);
+    // tiles never straddle split_n.  attn1's to_q | to_k | to_v as ONE GEMM: q | k row-major for the attention kernel,
+    // v transposed (OUT_F16_T) as its PV operand (ldm/modules/attention.py:180-186)
+    void* out2;
+    int split_n, out_kind2, ld_out2;
 };
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 void igemm_set_force_cfg(int cfg);   // process-wide override of the tile choice (0 = automatic)
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s);
+int igemm_stats_slots(const IgemmArgs& a);    // > 0: igemm_launch(a) will fill a.stats_out with that many slots per row; 0: it cannot
+int row_stats_slots(int C);                   // slots per row the separate pass writes: C / 160 (the epilogue's layout) or 1
+int row_stats_launch(const half_t* x, int rows, int C, float* stats /* [rows][row_stats_slots(C)][2] */, hipStream_t s);
 int igemm_splitk_factor(const IgemmArgs& a);                    // 1 = no split; else the engine must provide a.ws
 int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s);     // out = epilogue(sum_s ws[s])   // pipelined big-tile kernel (igemm2.hip)
 size_t igemm_npad(int n);   // rows the packed weight must provide

@@ -106,6 +106,8 @@ struct GemmW {              // packed [npad][K] fp16 weight + fp32 bias (packed 
     bool im2col = false;    // conv3x3 whose Cin is not a multiple of 64: K = roundup64(9 * cin_pad)
     int cin_pad = 0;
     int k_real = 0;         // un-padded contraction length (algorithmic flop accounting)
+    float* ln_u = nullptr;  // LayerNorm folded in: u[n] = sum_k W'[n][k] (packed order); bias then holds sum_k beta_k W_nk + b_n
+    float ln_eps = 1e-5f;
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -118,7 +120,7 @@ struct Layer {
     GemmW conv;                                            // L_CONV / L_DOWN / L_UP
     NormW gn1, gn2; GemmW c1, c2, skip; int emb_off = 0;   // L_RES
     NormW gn, ln1, ln2, ln3;                               // L_ATTN
-    GemmW pin, pout, qk1, v1, o1, q2, k2, v2, o2, ffp, ffo;
+    GemmW pin, pout, qkv1, o1, q2, k2, v2, o2, ffp, ffo;     // qkv1: attn1's to_q | to_k | to_v stacked (one GEMM)
 };
 typedef std::vector<Layer> Block;
 
@@ -241,6 +243,9 @@ struct fgdm_engine {
     std::unordered_map<std::string, std::vector<void*>> weight_allocs;
     std::unordered_map<std::string, bool> comp_dirty, comp_packed;
     std::string cur_comp;
+    // LayerNorms of the transformer blocks folded into the GEMMs they feed (default) or run as kernels of their own
+    // (FGDM_LN_FOLD=0 at fgdm_create: the A/B switch for tools/ab_bench.sh; numerics differ only in rounding points)
+    bool ln_fold = true;
     hipStream_t s = nullptr;      // stream of the call in flight
     Prof prof;
 
@@ -562,12 +567,12 @@ struct fgdm_engine {
     // kmap(k_packed) -> k_src or -1.  row_perm maps packed row -> stacked source row (GEGLU interleave).
     int pack_rows(GemmW& g, const std::vector<std::pair<const float*, int>>& srcs, int K_src, int K,
                   const std::vector<int>& kmap, const std::vector<const float*>& biases, bool geglu,
-                  const std::vector<float>& src_scale = {}) {
+                  const std::vector<float>& src_scale = {}, const float* ln_gamma = nullptr, const float* ln_beta = nullptr) {
         int N = 0;
         for (auto& s : srcs) N += s.second;
         const size_t npad = igemm_npad(N);
         std::vector<half_t> w(npad * (size_t)K, (half_t)0);
-        std::vector<float> bias(npad, 0.f);
+        std::vector<float> bias(npad, 0.f), lnu(ln_gamma ? npad : 0, 0.f);
         std::vector<const float*> rowp(N);
         std::vector<float> bflat(N, 0.f), rscale(N, 1.f);
         int r = 0;
@@ -586,6 +591,17 @@ struct fgdm_engine {
             const float* src = rowp[sr];
             const float rs = rscale[sr];
             half_t* dst = w.data() + (size_t)pr * K;
+            if (ln_gamma) {      // LayerNorm folded into this Linear: W' = fp16(gamma_k W_nk), u = sum_k W', bias += sum_k beta_k W_nk
+                double us = 0.0, cs = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    dst[k] = (half_t)(src[k] * rs * ln_gamma[k]);
+                    us += (double)(float)dst[k];
+                    cs += (double)ln_beta[k] * (double)(src[k] * rs);
+                }
+                lnu[pr] = (float)us;
+                bias[pr] = (float)((double)(bflat[sr] * rs) + cs);
+                continue;
+            }
             if (kmap.empty()) for (int k = 0; k < K; ++k) dst[k] = (half_t)(src[k] * rs);
             else for (int k = 0; k < K; ++k) if (kmap[k] >= 0) dst[k] = (half_t)(src[kmap[k]] * rs);
             bias[pr] = bflat[sr] * rs;
@@ -593,18 +609,29 @@ struct fgdm_engine {
         g.N = N; g.K = K; g.k_real = K_src;
         g.w = upload(w);
         g.bias = upload(bias);
-        return (g.w && g.bias) ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed while packing weights");
+        g.ln_u = ln_gamma ? upload(lnu) : nullptr;
+        if (ln_gamma && !kmap.empty()) return fail(FGDM_ERR_ARG, "LayerNorm fold: plain Linear weights only");
+        return (g.w && g.bias && (!ln_gamma || g.ln_u)) ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed while packing weights");
     }
-    int pack_linear(GemmW& g, const std::string& pre, bool has_bias, bool geglu = false, float wscale = 1.f) {
+    // ln: state-dict prefix of the LayerNorm whose output feeds this Linear (folded in, see IgemmArgs::ln_stats)
+    int pack_linear(GemmW& g, const std::string& pre, bool has_bias, bool geglu = false, float wscale = 1.f,
+                    const std::string& ln = std::string()) {
         const ParamSlot* w = slot(pre + ".weight");
         if (!w) return FGDM_ERR_STATE;
+        const ParamSlot *lg = nullptr, *lb = nullptr;
+        if (!ln.empty()) { lg = slot(ln + ".weight"); lb = slot(ln + ".bias"); if (!lg || !lb) return FGDM_ERR_STATE; }
         const ParamSlot* b = has_bias ? slot(pre + ".bias") : nullptr;
         if (has_bias && !b) return FGDM_ERR_STATE;
         const int N = (int)w->shape[0], K = (int)(w->numel() / w->shape[0]);
         if (K & 63) return fail(FGDM_ERR_ARG, "linear K not a multiple of 64: " + pre);
-        return pack_rows(g, {{w->host.data(), N}}, K, K, {}, {b ? b->host.data() : nullptr}, geglu, {wscale});
+        if (lg && (int)lg->numel() != K) return fail(FGDM_ERR_ARG, "LayerNorm fold: width mismatch for " + pre);
+        return pack_rows(g, {{w->host.data(), N}}, K, K, {}, {b ? b->host.data() : nullptr}, geglu, {wscale},
+                         lg ? lg->host.data() : nullptr, lb ? lb->host.data() : nullptr);
     }
-    int pack_stack(GemmW& g, const std::vector<std::string>& pres, bool has_bias, const std::vector<float>& scales = {}) {
+    int pack_stack(GemmW& g, const std::vector<std::string>& pres, bool has_bias, const std::vector<float>& scales = {},
+                   const std::string& ln = std::string()) {
+        const ParamSlot *lg = nullptr, *lb = nullptr;
+        if (!ln.empty()) { lg = slot(ln + ".weight"); lb = slot(ln + ".bias"); if (!lg || !lb) return FGDM_ERR_STATE; }
         std::vector<std::pair<const float*, int>> srcs;
         std::vector<const float*> biases;
         int K = 0;
@@ -615,7 +642,7 @@ struct fgdm_engine {
             srcs.push_back({w->host.data(), (int)w->shape[0]});
             if (has_bias) { const ParamSlot* b = slot(pre + ".bias"); if (!b) return FGDM_ERR_STATE; biases.push_back(b->host.data()); }
         }
-        return pack_rows(g, srcs, K, K, {}, biases, false, scales);
+        return pack_rows(g, srcs, K, K, {}, biases, false, scales, lg ? lg->host.data() : nullptr, lb ? lb->host.data() : nullptr);
     }
     // conv3x3 [Cout, Cin, 3, 3] -> k = tap * Cin + c (implicit GEMM) or im2col layout with padded Cin / K
     int pack_conv3(GemmW& g, const std::string& pre) {
@@ -667,20 +694,19 @@ struct fgdm_engine {
                     CHK(pack_norm(l.gn, p + "norm"));
                     CHK(pack_linear(l.pin, p + "proj_in", true));
                     CHK(pack_linear(l.pout, p + "proj_out", true));
-                    CHK(pack_norm(l.ln1, t + "norm1"));
-                    CHK(pack_norm(l.ln2, t + "norm2"));
-                    CHK(pack_norm(l.ln3, t + "norm3"));
                     // softmax(q k^T d^-1/2) is evaluated as exp2 of (q log2(e) d^-1/2) k^T: the constant is folded into the
                     // to_q weights here, in fp32, so the scaled query carries ONE fp16 rounding (attention.py:190-193)
                     const float qs = 1.4426950408889634f / sqrtf((float)(l.cin / l.heads));
-                    CHK(pack_stack(l.qk1, {t + "attn1.to_q", t + "attn1.to_k"}, false, {qs, 1.f}));
-                    CHK(pack_linear(l.v1, t + "attn1.to_v", false));
+                    // norm1 / norm2 / norm3 are folded into the Linears they feed (no normalised copy of the tokens is ever stored)
+                    const std::string n1 = ln_fold ? t + "norm1" : "", n2 = ln_fold ? t + "norm2" : "", n3 = ln_fold ? t + "norm3" : "";
+                    if (!ln_fold) { CHK(pack_norm(l.ln1, t + "norm1")); CHK(pack_norm(l.ln2, t + "norm2")); CHK(pack_norm(l.ln3, t + "norm3")); }
+                    CHK(pack_stack(l.qkv1, {t + "attn1.to_q", t + "attn1.to_k", t + "attn1.to_v"}, false, {qs, 1.f, 1.f}, n1));
                     CHK(pack_linear(l.o1, t + "attn1.to_out.0", true));
-                    CHK(pack_linear(l.q2, t + "attn2.to_q", false, false, qs));
+                    CHK(pack_linear(l.q2, t + "attn2.to_q", false, false, qs, n2));
                     CHK(pack_linear(l.k2, t + "attn2.to_k", false));
                     CHK(pack_linear(l.v2, t + "attn2.to_v", false));
                     CHK(pack_linear(l.o2, t + "attn2.to_out.0", true));
-                    CHK(pack_linear(l.ffp, t + "ff.net.0.proj", true, true));
+                    CHK(pack_linear(l.ffp, t + "ff.net.0.proj", true, true, 1.f, n3));
                     CHK(pack_linear(l.ffo, t + "ff.net.2", true));
                     break;
                 }
@@ -812,7 +838,11 @@ struct fgdm_engine {
     }
     void tfree(Tensor& t) { arena.release(t.p); t.p = nullptr; }
 
+    // LayerNorm partial sums of a token matrix (IgemmArgs::stats_out / ln_stats): [rows][slots][2] floats in the arena
+    struct LnStats { float* p = nullptr; int slots = 0; };
     struct Epi {
+        const LnStats* ln = nullptr;   // the A operand is to be LayerNorm-ed: the weights have it folded in (GemmW::ln_u)
+        LnStats* stats = nullptr;      // also produce the partial sums of the OUTPUT rows (for the next folded LayerNorm)
         int act = ACT_NONE;
         const float* rowvec = nullptr; int rv_stride = 0;
         const half_t* resid = nullptr; int ld_res = 0;
@@ -820,6 +850,7 @@ struct fgdm_engine {
         int out_kind = OUT_F16;
         void* out = nullptr;   // override destination (OUT_F32* kinds or in-place adds)
         int ld_out = 0;
+        void* out2 = nullptr; int out_kind2 = OUT_F16, ld_out2 = 0, split_n = 0;   // second destination (IgemmArgs::out2)
         int rps = 0;           // rows per sample override
     };
     // out = epilogue(A W^T): LINEAR over rows of x0 (x1 = virtual concat), or conv3x3 in `mode`
@@ -841,6 +872,7 @@ struct fgdm_engine {
         a.ld_out = e.ld_out ? e.ld_out : nout;
         a.rows_per_sample = e.rps ? e.rps : Ho * Wo;
         a.scale = e.scale;
+        a.out2 = e.out2; a.out_kind2 = e.out_kind2; a.ld_out2 = e.ld_out2; a.split_n = e.split_n;
         const int taps = mode == IG_LINEAR ? 1 : 9;
         if (taps * (a.C0 + a.C1) != a.K) return fail(FGDM_ERR_ARG, "gemm: K mismatch");
         if (!a.out) return fail(FGDM_ERR_NOMEM, "gemm: null output (workspace exhausted?)");
@@ -851,15 +883,34 @@ struct fgdm_engine {
             a.ws = (float*)arena.alloc((size_t)a.splitk * a.M * a.N * sizeof(float));
             if (!a.ws) return fail(FGDM_ERR_NOMEM, "workspace (split-K partials)");
         }
+        if (e.ln) {
+            if (!w.ln_u || !e.ln->p || a.splitk > 1) return fail(FGDM_ERR_STATE, "gemm: LayerNorm fold without folded weights / statistics");
+            a.ln_stats = e.ln->p; a.ln_slots = e.ln->slots; a.ln_u = w.ln_u; a.ln_eps = w.ln_eps;
+        } else if (w.ln_u) {
+            return fail(FGDM_ERR_STATE, "gemm: these weights have a LayerNorm folded in; statistics are required");
+        }
+        if (e.stats) {     // partial sums of the output rows: from the GEMM's own epilogue when its kernel can, else one more pass
+            e.stats->slots = igemm_stats_slots(a);
+            e.stats->p = (float*)arena.alloc((size_t)a.M * std::max(e.stats->slots, row_stats_slots(nout)) * 2 * sizeof(float));
+            if (!e.stats->p) return fail(FGDM_ERR_NOMEM, "workspace (LayerNorm statistics)");
+            if (e.stats->slots) a.stats_out = e.stats->p;
+        }
         prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real, tag);
         if (prof.armed) {   // operands once: activations + weights + residual + output
             const double in_b = 2.0 * ((double)x0.numel() + (x1 ? (double)x1->numel() : 0.0));
             const double out_b = (double)a.M * nout * (e.out_kind == OUT_F16 || e.out_kind == OUT_F16_T ? 2.0 : 4.0);
             prof.bytes[PC_IGEMM] += in_b + 2.0 * (double)w.N * w.K + out_b + (e.resid ? 2.0 * (double)a.M * nout : 0.0);
         }
-        const int rc = igemm_launch(a, s);
+        int rc = igemm_launch(a, s);
         prof.end(s);
         if (a.ws) arena.release(a.ws);
+        if (rc == FGDM_OK && e.stats && e.stats->slots == 0) {
+            if (a.out_kind != OUT_F16 || a.ld_out != nout) return fail(FGDM_ERR_ARG, "gemm: row statistics need a dense fp16 output");
+            e.stats->slots = row_stats_slots(nout);
+            prof.begin(PC_NORM, s, 2.0 * (double)a.M * nout, "row_stats");
+            rc = row_stats_launch((const half_t*)a.out, a.M, nout, e.stats->p, s);
+            prof.end(s);
+        }
         return rc == FGDM_OK ? rc : fail(rc, "igemm launch failed");
     }
     // conv3x3 (stride 1/2, or on the nearest-2x upsampled input) -> new tensor
@@ -1008,19 +1059,26 @@ struct fgdm_engine {
         Tensor x = x_in, x_full;
         int B = x.B;
         const int T = x.H * x.W, C = x.C, d = C / l.heads;
-        Tensor g, h, n, qk, vt, a, h2, q2, k2, v2t, f;
+        Tensor g, h, qk, vt, a, h2, q2, k2, v2t, f;
+        LnStats s1, s2, s3;      // row sums of h / h2 / h3 for norm1 / norm2 / norm3, which live inside the next GEMMs
         CHK(gnorm(l.gn, x, nullptr, 1e-6f, false, &g));
-        CHK(linear(l.pin, g, Epi{}, &h));
+        Tensor nrm;                 // FGDM_LN_FOLD=0 only: the normalised tokens as a tensor of their own
+        { Epi e; if (ln_fold) e.stats = &s1; CHK(linear(l.pin, g, e, &h)); }
         tfree(g);
-        // --- attn1 (self)
-        CHK(lnorm(l.ln1, h, &n));
-        CHK(linear(l.qk1, n, Epi{}, &qk));
+        // --- attn1 (self): q | k and v^T straight from h, norm1 folded into both projections
+        if (!ln_fold) CHK(lnorm(l.ln1, h, &nrm));
+        const Tensor& a1 = ln_fold ? h : nrm;
+        // ONE GEMM for to_q | to_k | to_v: q | k row-major [M, 2C], v transposed [B, C, Tp] (the attention kernel's PV operand)
         const int Tp = roundup(T, 64);
+        qk = talloc(B, x.H, x.W, 2 * C);
         vt = talloc(B, 1, C, Tp);
-        if (!vt.p) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (!qk.p || !vt.p) return fail(FGDM_ERR_NOMEM, "workspace");
         if (Tp != T) HIP_TRY(hipMemsetAsync(vt.p, 0, vt.numel() * sizeof(half_t), s));
-        { Epi e; e.out_kind = OUT_F16_T; e.out = vt.p; e.ld_out = Tp; e.rps = T; CHK(linear(l.v1, n, e, nullptr)); }
-        tfree(n);
+        { Epi e; if (ln_fold) e.ln = &s1; e.out = qk.p; e.ld_out = 2 * C; e.rps = T;
+          e.out2 = vt.p; e.out_kind2 = OUT_F16_T; e.ld_out2 = Tp; e.split_n = 2 * C;
+          CHK(linear(l.qkv1, a1, e, nullptr)); }
+        if (s1.p) arena.release(s1.p);
+        if (nrm.p) tfree(nrm);
         a = talloc(B, x.H, x.W, C);
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
         { char tag[56]; snprintf(tag, sizeof(tag), "attn B%d T%d Tk%d d%d", B, T, T, d);
@@ -1029,18 +1087,27 @@ struct fgdm_engine {
           prof.end(s);
           if (rc != FGDM_OK) return fail(rc, "attention launch failed (unsupported head dim?)"); }
         tfree(qk); tfree(vt);
-        { Epi e; e.resid = h.p; e.ld_res = C; CHK(linear(l.o1, a, e, &h2)); }
+        { Epi e; e.resid = h.p; e.ld_res = C; if (ln_fold) e.stats = &s2; CHK(linear(l.o1, a, e, &h2)); }
         tfree(a); tfree(h);
         if (dup) {     // from here on the two halves differ (their contexts do)
-            Tensor f;
-            CHK(dup_rows(h2, &f)); tfree(h2); h2 = f;
+            Tensor f2;
+            CHK(dup_rows(h2, &f2)); tfree(h2); h2 = f2;
             CHK(dup_rows(x, &x_full)); x = x_full;
             B *= 2;
         }
-        // --- attn2 (cross, 77-token context)
-        CHK(lnorm(l.ln2, h2, &n));
-        CHK(linear(l.q2, n, Epi{}, &q2));
-        tfree(n);
+        if (dup && ln_fold) {
+            const size_t sb = (size_t)(B / 2) * T * s2.slots * 2 * sizeof(float);
+            float* s2f = (float*)arena.alloc(2 * sb);
+            if (!s2f) return fail(FGDM_ERR_NOMEM, "workspace");
+            HIP_TRY(hipMemcpyAsync(s2f, s2.p, sb, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync((char*)s2f + sb, s2.p, sb, hipMemcpyDeviceToDevice, s));
+            arena.release(s2.p); s2.p = s2f;
+        }
+        // --- attn2 (cross, 77-token context), norm2 folded into to_q
+        if (!ln_fold) CHK(lnorm(l.ln2, h2, &nrm));
+        { Epi e; if (ln_fold) e.ln = &s2; CHK(linear(l.q2, ln_fold ? h2 : nrm, e, &q2)); }
+        if (s2.p) arena.release(s2.p);
+        if (nrm.p) tfree(nrm);
         int Tk, Tkp;
         const bool cached = (ctx16.p == nullptr);
         if (cached) {      // K / V^T were projected once by set_context
@@ -1061,12 +1128,13 @@ struct fgdm_engine {
           if (rc != FGDM_OK) return fail(rc, "attention launch failed"); }
         tfree(q2);
         if (!cached) { tfree(k2); tfree(v2t); }
-        { Epi e; e.resid = h2.p; e.ld_res = C; CHK(linear(l.o2, a, e, &h)); }
+        { Epi e; e.resid = h2.p; e.ld_res = C; if (ln_fold) e.stats = &s3; CHK(linear(l.o2, a, e, &h)); }
         tfree(a); tfree(h2);
-        // --- GEGLU feed-forward
-        CHK(lnorm(l.ln3, h, &n));
-        { Epi e; e.act = ACT_GEGLU; CHK(linear(l.ffp, n, e, &f)); }
-        tfree(n);
+        // --- GEGLU feed-forward, norm3 folded into the projection
+        if (!ln_fold) CHK(lnorm(l.ln3, h, &nrm));
+        { Epi e; if (ln_fold) e.ln = &s3; e.act = ACT_GEGLU; CHK(linear(l.ffp, ln_fold ? h : nrm, e, &f)); }
+        if (s3.p) arena.release(s3.p);
+        if (nrm.p) tfree(nrm);
         { Epi e; e.resid = h.p; e.ld_res = C; CHK(linear(l.ffo, f, e, &h2)); }
         tfree(f); tfree(h);
         { Epi e; e.resid = x.p; e.ld_res = C; CHK(linear(l.pout, h2, e, out)); }
@@ -1712,6 +1780,7 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
     int rc = make_desc(cfg, &e);
     if (rc != FGDM_OK) { g_create_err = "unsupported configuration"; return rc; }
     e->device = device;
+    if (const char* v = getenv("FGDM_LN_FOLD")) e->ln_fold = atoi(v) != 0;
     rc = e->ensure_device();
     if (rc != FGDM_OK) {
         g_create_err = e->err + " [" + hipGetErrorString(hipGetLastError()) + "]";
@@ -2073,6 +2142,65 @@ int fgdm_op_linear(const void* x, const float* w, const float* bias, const void*
     return rc;
 }
 
+// h = x W1^T + b1 (+ resid), fp16, with the LayerNorm partial sums of its rows produced on the way (from the GEMM's own
+// epilogue when the chosen kernel can, else by row_stats), then y = act(LayerNorm(h) W2^T + b2) with the LayerNorm folded
+// into the second GEMM: the producer / consumer pair of every transformer-block LayerNorm (attention.py:234-240).
+// *slots_used receives the number of partial-sum slots per row (1 = the separate row_stats pass ran).
+int fgdm_op_linear_ln_linear(const void* x, const float* w1, const float* b1, const void* resid, const float* gamma,
+                             const float* beta, const float* w2, const float* b2, int M, int K1, int C, int N2, int act2,
+                             void* h_out, void* y_out, int* slots_used, void* stream) {
+    if (!x || !w1 || !gamma || !beta || !w2 || !h_out || !y_out || (K1 & 63) || (C & 63)) return FGDM_ERR_ARG;
+    hipStream_t s = as_stream(stream);
+    auto host = [](const float* d, size_t n, std::vector<float>& v) { v.resize(n); return hipMemcpy(v.data(), d, n * sizeof(float), hipMemcpyDefault) == hipSuccess; };
+    std::vector<float> W1, B1(C, 0.f), G, Bt, W2, B2(N2, 0.f);
+    if (!host(w1, (size_t)C * K1, W1) || !host(gamma, C, G) || !host(beta, C, Bt) || !host(w2, (size_t)N2 * C, W2)) return FGDM_ERR_HIP;
+    if (b1 && !host(b1, C, B1)) return FGDM_ERR_HIP;
+    if (b2 && !host(b2, N2, B2)) return FGDM_ERR_HIP;
+    const size_t np1 = igemm_npad(C), np2 = igemm_npad(N2);
+    std::vector<half_t> p1(np1 * (size_t)K1, (half_t)0), p2(np2 * (size_t)C, (half_t)0);
+    std::vector<float> bp1(np1, 0.f), bp2(np2, 0.f), u2(np2, 0.f);
+    for (int n = 0; n < C; ++n) { bp1[n] = B1[n]; for (int k = 0; k < K1; ++k) p1[(size_t)n * K1 + k] = (half_t)W1[(size_t)n * K1 + k]; }
+    for (int pr = 0; pr < N2; ++pr) {
+        int sr = pr;
+        if (act2 == ACT_GEGLU) { const int grp = pr >> 6, within = pr & 63; sr = within < 32 ? grp * 32 + within : N2 / 2 + grp * 32 + (within - 32); }
+        double us = 0.0, cs = 0.0;
+        for (int k = 0; k < C; ++k) {
+            const half_t wq = (half_t)(W2[(size_t)sr * C + k] * G[k]);
+            p2[(size_t)pr * C + k] = wq;
+            us += (double)(float)wq;
+            cs += (double)Bt[k] * (double)W2[(size_t)sr * C + k];
+        }
+        u2[pr] = (float)us;
+        bp2[pr] = (float)((double)B2[sr] + cs);
+    }
+    TmpDev tmp;
+    IgemmArgs a{};
+    a.A0 = (const half_t*)x; a.C0 = K1; a.Wt = tmp.up(p1); a.bias = tmp.up(bp1); a.zero = g_zero_page();
+    a.resid = (const half_t*)resid; a.ld_res = C;
+    a.B = 1; a.H = 1; a.W = M; a.Ho = 1; a.Wo = M; a.M = M; a.N = C; a.K = K1; a.mode = IG_LINEAR; a.act = ACT_NONE;
+    a.out_kind = OUT_F16; a.out = h_out; a.ld_out = C; a.rows_per_sample = M; a.scale = 1.f;
+    if (!a.Wt || !a.bias || !a.zero) return FGDM_ERR_NOMEM;
+    int slots = igemm_stats_slots(a);
+    float* stats = nullptr;
+    if (hipMalloc(&stats, (size_t)M * std::max(slots, row_stats_slots(C)) * 2 * sizeof(float)) != hipSuccess) return FGDM_ERR_NOMEM;
+    tmp.ptrs.push_back(stats);
+    if (slots) a.stats_out = stats;
+    int rc = igemm_launch(a, s);
+    if (rc == FGDM_OK && !slots) { slots = row_stats_slots(C); rc = row_stats_launch((const half_t*)h_out, M, C, stats, s); }
+    if (slots_used) *slots_used = a.stats_out ? slots : -slots;      // negative: the separate pass produced them
+    if (rc != FGDM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    IgemmArgs b{};
+    b.A0 = (const half_t*)h_out; b.C0 = C; b.Wt = tmp.up(p2); b.bias = tmp.up(bp2); b.zero = a.zero;
+    b.ln_stats = stats; b.ln_slots = slots; b.ln_u = tmp.up(u2); b.ln_eps = 1e-5f;
+    const int nout = act2 == ACT_GEGLU ? N2 / 2 : N2;
+    b.B = 1; b.H = 1; b.W = M; b.Ho = 1; b.Wo = M; b.M = M; b.N = N2; b.K = C; b.mode = IG_LINEAR; b.act = act2;
+    b.out_kind = OUT_F16; b.out = y_out; b.ld_out = nout; b.rows_per_sample = M; b.scale = 1.f;
+    if (!b.Wt || !b.bias || !b.ln_u) return FGDM_ERR_NOMEM;
+    rc = igemm_launch(b, s);
+    (void)hipStreamSynchronize(s);
+    return rc;
+}
+
 int fgdm_debug_force_igemm_cfg(int cfg) { igemm_set_force_cfg(cfg); return FGDM_OK; }
 
 // Micro-benchmark of one conv / linear shape on random data: average device ms over `iters` launches.
@@ -2124,6 +2252,37 @@ int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, i
     for (int i = 0; i < 3 && rc == FGDM_OK; ++i) rc = igemm_launch(a, nullptr);
     HIP_TRY(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters && rc == FGDM_OK; ++i) rc = igemm_launch(a, nullptr);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// Micro-benchmark of the fused attention kernel on random data: average device ms over `iters` launches.
+int fgdm_bench_attention(int B, int heads, int T, int Tk, int d, int iters, float* avg_ms) {
+    if (!avg_ms || iters <= 0 || B <= 0 || heads <= 0 || T <= 0 || Tk <= 0) return FGDM_ERR_ARG;
+    const int C = heads * d, Tkp = (Tk + 63) / 64 * 64;
+    unsigned st = 4242u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 9) & 0xffff) / 32768.0f - 1.0f; };
+    std::vector<half_t> hq((size_t)B * T * C), hk((size_t)B * Tk * C), hv((size_t)B * C * Tkp, (half_t)0);
+    for (auto& v : hq) v = (half_t)(rnd() * 1.5f);
+    for (auto& v : hk) v = (half_t)(rnd() * 1.5f);
+    for (size_t r = 0; r < (size_t)B * C; ++r) for (int t = 0; t < Tk; ++t) hv[r * Tkp + t] = (half_t)rnd();
+    TmpDev tmp;
+    half_t* o = nullptr;
+    if (hipMalloc(&o, (size_t)B * T * C * sizeof(half_t)) != hipSuccess) return FGDM_ERR_NOMEM;
+    tmp.ptrs.push_back(o);
+    const half_t *dq = tmp.up(hq), *dk = tmp.up(hk), *dv = tmp.up(hv);
+    if (!dq || !dk || !dv) return FGDM_ERR_NOMEM;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = FGDM_OK;
+    for (int i = 0; i < 3 && rc == FGDM_OK; ++i) rc = attention_launch(dq, C, dk, C, dv, Tkp, o, C, B, heads, T, Tk, d, 0, nullptr);
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && rc == FGDM_OK; ++i) rc = attention_launch(dq, C, dk, C, dv, Tkp, o, C, B, heads, T, Tk, d, 0, nullptr);
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -33,6 +33,15 @@ __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
 }
 
+// rstd (acc - mean u): one fma and one multiply that must NOT be contracted with the bias add that follows -- the pipelined
+// kernel (igemm2.hip ln_fix) rounds in exactly this sequence, and which kernel runs a layer must not change a bit
+__device__ __forceinline__ float ln_scale(float acc, float mean, float rstd, float u) {
+    float t, w;      // inline asm: opaque to the backend's multiply-add fusion (-ffp-contract=fast)
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(-mean), "v"(u), "v"(acc));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(w) : "v"(rstd), "v"(t));
+    return w;
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) {
     constexpr int T = WM * WN * 64;
@@ -172,8 +181,48 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
 
     // ---------------------------------------------------------------- epilogue
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (a.ln_stats) {
+        // LayerNorm folded into this GEMM (see IgemmArgs): acc <- rstd (acc - mean u); the bias (which carries beta W) follows
+        // below.  (mean, rstd) of the 16 rows this lane holds per row tile, from the partial sums in fixed slot order.
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float sm[16], sq[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sq[r] = 0.f; }
+            for (int p = 0; p < a.ln_slots; ++p) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < a.M) {
+                        const float* sp = a.ln_stats + ((size_t)row * a.ln_slots + p) * 2;
+                        sm[r] += sp[0]; sq[r] += sp[1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double mu = (double)sm[r] / (double)a.C0;
+                double var = (double)sq[r] / (double)a.C0 - mu * mu;
+                if (var < 0.0) var = 0.0;
+                sm[r] = (float)mu;
+                sq[r] = (float)(1.0 / sqrt(var + (double)a.ln_eps));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pc = n0 + wn * TN + j * 32 + (lane & 31);
+                const float un = pc < a.N ? a.ln_u[pc] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = ln_scale(acc[i][j][r], sm[r], sq[r], un);   // + bias below
+            }
+        }
+    }
     const int rps = a.rows_per_sample;
     const bool geglu = (a.act == ACT_GEGLU);
+    // destination of this tile (block-uniform): the second one for packed columns >= split_n (see IgemmArgs::out2)
+    const bool second = a.out2 && n0 >= a.split_n;
+    void* const outp = second ? a.out2 : a.out;
+    const int okind = second ? a.out_kind2 : a.out_kind, ldo = second ? a.ld_out2 : a.ld_out;
+    const int ncol0 = second ? a.split_n : 0, nchan = (a.out2 ? (second ? a.N : a.split_n) : a.N) - ncol0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -184,7 +233,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
             const float bias = a.bias ? a.bias[pcol] : 0.f;
             float gbias = 0.f;
             if (geglu) gbias = a.bias ? a.bias[pcol + 32] : 0.f;
-            const int ocol = geglu ? ((pcol >> 6) << 5) + lrow : pcol;
+            const int ocol = geglu ? ((pcol >> 6) << 5) + lrow : pcol - ncol0;
             // per-sample emb values for this lane's 16 rows: all loads issued before any store (stores to `out`
             // may alias for the compiler and would otherwise serialise each load behind the previous store)
             float rvv[16];
@@ -209,8 +258,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
                     }
                     v[e] = x * a.scale;
                 }
-                if (a.out_kind == OUT_F16) {
-                    half_t* o = (half_t*)a.out;
+                if (okind == OUT_F16) {
+                    half_t* o = (half_t*)outp;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int row = row0 + e;
@@ -219,26 +268,26 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
                             // residual is added in fp32 and the sum rounded -- identical in every kernel of the family
                             half_t x = (half_t)v[e];
                             if (a.resid) x = (half_t)((float)x + (float)a.resid[(size_t)row * a.ld_res + ocol]);
-                            o[(size_t)row * a.ld_out + ocol] = x;
+                            o[(size_t)row * ldo + ocol] = x;
                         }
                     }
-                } else if (a.out_kind == OUT_F32) {
-                    float* o = (float*)a.out;
+                } else if (okind == OUT_F32) {
+                    float* o = (float*)outp;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (row0 + e < a.M) o[(size_t)(row0 + e) * a.ld_out + ocol] = v[e];
+                        if (row0 + e < a.M) o[(size_t)(row0 + e) * ldo + ocol] = v[e];
                 } else {
                     // transposed outputs: [b][col][t]; ld_out = elements per (b, col) row
                     const bool vec = ((rps & 3) == 0) && (row0 + 3 < a.M);
                     if (vec) {
                         const int b = row0 / rps, t = row0 - b * rps;
-                        const size_t off = ((size_t)b * a.N + ocol) * a.ld_out + t;
-                        if (a.out_kind == OUT_F16_T) {
+                        const size_t off = ((size_t)b * nchan + ocol) * ldo + t;
+                        if (okind == OUT_F16_T) {
                             h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                            *(h4*)((half_t*)a.out + off) = pk;
+                            *(h4*)((half_t*)outp + off) = pk;
                         } else {
                             f32x4 pk = {v[0], v[1], v[2], v[3]};
-                            *(f32x4*)((float*)a.out + off) = pk;
+                            *(f32x4*)((float*)outp + off) = pk;
                         }
                     } else {
 #pragma unroll
@@ -246,9 +295,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
                             const int row = row0 + e;
                             if (row < a.M) {
                                 const int b = row / rps, t = row - b * rps;
-                                const size_t off = ((size_t)b * a.N + ocol) * a.ld_out + t;
-                                if (a.out_kind == OUT_F16_T) ((half_t*)a.out)[off] = (half_t)v[e];
-                                else ((float*)a.out)[off] = v[e];
+                                const size_t off = ((size_t)b * nchan + ocol) * ldo + t;
+                                if (okind == OUT_F16_T) ((half_t*)outp)[off] = (half_t)v[e];
+                                else ((float*)outp)[off] = v[e];
                             }
                         }
                     }
@@ -280,16 +329,10 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 static int g_force_cfg = 0;
 void igemm_set_force_cfg(int cfg) { g_force_cfg = cfg; }
 
-int igemm_launch(const IgemmArgs& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 63) || (a.C0 & 63) || (a.C1 & 63)) return FGDM_ERR_ARG;
-    if (a.act == ACT_GEGLU && (a.N & 63)) return FGDM_ERR_ARG;
+// tile configuration for `a` (0 = the 2-stage kernel picks one of its own tiles; 4..9 = pipelined kernel cfg 0..5)
+static int pick_force(const IgemmArgs& a) {
     int force = a.force_cfg ? a.force_cfg : g_force_cfg;
     if (a.act == ACT_QGELU && force >= 4) force = 0;   // the pipelined kernel's epilogue does not carry quick-GELU
-    if (a.splitk > 1) {        // split-K plan made by the caller (igemm_splitk_factor): 128x320 tiles + reduction pass
-        if (!a.ws) return FGDM_ERR_ARG;
-        const int rc = igemm2_launch(a, 2, s);
-        return rc == FGDM_OK ? igemm_splitk_reduce(a, s) : rc;
-    }
     if (force == 0) {
         const bool geglu = a.act == ACT_GEGLU;
         if (!geglu && a.N % 320 == 0) {
@@ -301,6 +344,29 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
             force = 5;
         }
     }
+    return force;
+}
+
+// Will igemm_launch(a) write LayerNorm partial sums into a.stats_out, and how many slots per row?  Only the pipelined
+// kernel's 320-column tiles do (two 160-column wave tiles each); otherwise 0 and the caller runs row_stats_launch.
+int igemm_stats_slots(const IgemmArgs& a) {
+    if (a.out_kind != OUT_F16 || a.act == ACT_GEGLU || a.splitk > 1 || (a.N % 320) || (a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return 0;
+    const int f = pick_force(a);
+    return (f == 4 || f == 6 || f == 7 || f == 9) ? a.N / 160 : 0;
+}
+
+int igemm_launch(const IgemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 63) || (a.C0 & 63) || (a.C1 & 63)) return FGDM_ERR_ARG;
+    if (a.act == ACT_GEGLU && (a.N & 63)) return FGDM_ERR_ARG;
+    if (a.ln_stats && (a.mode != IG_LINEAR || a.C1 || a.ln_slots <= 0 || !a.ln_u)) return FGDM_ERR_ARG;
+    if (a.stats_out && igemm_stats_slots(a) == 0) return FGDM_ERR_ARG;
+    if (a.out2 && (a.act == ACT_GEGLU || a.splitk > 1 || a.stats_out || a.split_n <= 0 || a.split_n >= a.N || (a.split_n % 640))) return FGDM_ERR_ARG;
+    if (a.splitk > 1) {        // split-K plan made by the caller (igemm_splitk_factor): 128x320 tiles + reduction pass
+        if (!a.ws || a.ln_stats) return FGDM_ERR_ARG;
+        const int rc = igemm2_launch(a, 2, s);
+        return rc == FGDM_OK ? igemm_splitk_reduce(a, s) : rc;
+    }
+    int force = pick_force(a);
     // diagnostic knob for A/B runs (tools/ab_bench.sh): automatic choices take the 32x32x16 instantiations
     static const bool mfma32 = getenv("FGDM_IGEMM_MFMA32") && atoi(getenv("FGDM_IGEMM_MFMA32")) != 0;
     if (mfma32 && force >= 4 && force <= 6 && !a.force_cfg && !g_force_cfg) force += 3;

@@ -41,6 +41,17 @@ __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
 }
 
+// rstd (acc - mean u) + b with a FIXED rounding sequence (one fma, one multiply, one add; no contraction), the same in the
+// 2-stage kernel: which kernel evaluates a layer must not change a bit of its output
+__device__ __forceinline__ float ln_fix(float acc, float mean, float rstd, float u, float b) {
+    // inline asm: with -ffp-contract=fast the backend fuses a multiply into a following add whatever the source says
+    float t, w, r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(-mean), "v"(u), "v"(acc));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(w) : "v"(rstd), "v"(t));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(w), "v"(b));
+    return r;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -195,12 +206,31 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     // ---- epilogue operands (bias, per-sample emb rows) into LDS now, so the epilogue never waits on global loads
     float* bias_l = (float*)(smem + RING_BYTES);
     float* rv_l = bias_l + BN;
+    float* mr_l = rv_l + RV_MAX * BN;        // [BM][2] (mean, rstd) of the A rows: LayerNorm folded into this GEMM
+    float* u_l = mr_l + 2 * BM;              // [BN]    sum_k W'[n][k]
     const int rps = a.rows_per_sample;
     const int smp0 = m0 / rps;
     const int last_row = min(m0 + BM, a.M) - 1;
     const int nsmp = a.rowvec ? last_row / rps - smp0 + 1 : 0;
     const bool rv_in_lds = nsmp <= RV_MAX;
     for (int c = tid; c < BN; c += T) bias_l[c] = a.bias ? a.bias[n0 + c] : 0.f;
+    if (a.ln_stats) {
+        for (int c = tid; c < BN; c += T) u_l[c] = a.ln_u[n0 + c];
+        for (int r = tid; r < BM; r += T) {      // partial sums in fixed slot order; E[x^2] - mean^2 in double
+            float mean = 0.f, rstd = 0.f;
+            if (m0 + r < a.M) {
+                const float* sp = a.ln_stats + (size_t)(m0 + r) * a.ln_slots * 2;
+                float sm = 0.f, sq = 0.f;       // fp32 in slot order: the same additions as the 2-stage kernel's epilogue
+                for (int p = 0; p < a.ln_slots; ++p) { sm += sp[2 * p]; sq += sp[2 * p + 1]; }
+                const double mu = (double)sm / (double)a.C0;
+                double var = (double)sq / (double)a.C0 - mu * mu;
+                if (var < 0.0) var = 0.0;
+                mean = (float)mu;
+                rstd = (float)(1.0 / sqrt(var + (double)a.ln_eps));
+            }
+            mr_l[2 * r] = mean; mr_l[2 * r + 1] = rstd;
+        }
+    }
     if (a.rowvec && rv_in_lds)
         for (int c = tid; c < nsmp * BN; c += T) {
             const int sidx = c / BN, ch = c - sidx * BN;
@@ -220,6 +250,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     //     refill + fragment-read phase is LONGER than the MFMA phase, so pairing them does not hide it
     //     (the stagger lifts the no-global-load ablation from 1044 to 1187 TF/s but loses it again to the LDS-DMA
     //      fill path: 207 us compute-only, +46 us for the load instructions alone, +76 us for their memory traffic)
+    //   round 2: TWO 4-wave workgroups per CU (128x320 / 128x256 tiles, 2-stage ring, 66 KB LDS each) for the short-K
+    //     linears, so that one workgroup's store-bound epilogue overlaps the other's operand stream: L0 320->320 65 vs 66 us,
+    //     qk 320->640 116 vs 111, GEGLU 320->2560 427 vs 421 -- no gain; these layers sit at ~3.9 TB/s of HBM traffic either way
     auto wait_stage = [&](int k_needed) {     // stage k_needed landed; younger stages of this wave may stay in flight
         const int younger = min(nk - 1 - k_needed, STAGES - 2);
         if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LPS>();
@@ -293,8 +326,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     constexpr int WB_IT = (32 * CPR + 63) / 64;          // writeback iterations per lane
     static_assert(!GEGLU || NI % 2 == 0, "GEGLU needs value/gate tile pairs");
     char* cst = smem + wave * (32 * PITCH);
-    const int ocol0 = GEGLU ? ((n0 + wn * TN) >> 1) : (n0 + wn * TN);   // first output column of this wave
-    const int nvalid = GEGLU ? a.N / 2 : a.N;                            // valid output columns overall
+    // destination of this tile (block-uniform): the second one for packed columns >= split_n
+    const bool second = a.out2 && n0 >= a.split_n;
+    void* const outp = second ? a.out2 : a.out;
+    const int okind = second ? a.out_kind2 : a.out_kind, ldo = second ? a.ld_out2 : a.ld_out;
+    const int ncol0 = second ? a.split_n : 0, nend = a.out2 ? (second ? a.N : a.split_n) : a.N;
+    const int ocol0 = GEGLU ? ((n0 + wn * TN) >> 1) : (n0 + wn * TN - ncol0);   // first output column of this wave
+    const int nvalid = GEGLU ? a.N / 2 : nend - ncol0;                          // valid output columns of the destination
     const float* bw = bias_l + wn * TN;                                  // this wave's slice of the staged bias
 
     constexpr int PT = 32 / MS;                          // MFMA pixel tiles per 32-pixel staging pass
@@ -308,6 +346,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         const int row = m0 + wm * TM + ip * 32 + prow;    // ... and in the whole problem
         const int bsmp = (a.rowvec && row < a.M) ? row / rps : smp0;
         const float* rw = rv_l + (bsmp - smp0) * BN + wn * TN;
+        const int trow = wm * TM + ip * 32 + prow;           // row inside the tile
+        const float ln_mean = a.ln_stats ? mr_l[2 * trow] : 0.f, ln_rstd = a.ln_stats ? mr_l[2 * trow + 1] : 1.f;
+        const float* uw = u_l + wn * TN;
         // ---- registers -> (bias, emb, activation, scale) -> fp16 -> LDS [pixel][channel]
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -317,8 +358,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 const int wc = j * MS + (MS == 32 ? 8 * g : 0) + lq;      // packed channel inside the wave tile
                 const f32x4 bq = *(const f32x4*)(bw + wc);
                 float v[4];
+                if (a.ln_stats) {
+                    const f32x4 uq = *(const f32x4*)(uw + wc);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e] + bq[e];
+                    for (int e = 0; e < 4; ++e) v[e] = ln_fix(acc[j][i][g * 4 + e], ln_mean, ln_rstd, uq[e], bq[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e] + bq[e];
+                }
                 if (a.rowvec) {
                     if (rv_in_lds) {
                         const f32x4 rq = *(const f32x4*)(rw + wc);
@@ -339,36 +386,42 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 if constexpr (GEGLU) {      // packed rows: 64-row groups [32 value | 32 gate]
                     constexpr int GJ = MS == 32 ? 1 : 2;                 // gate tile = value tile + GJ
                     const f32x4 gq = *(const f32x4*)(bw + wc + 32);
+                    if (a.ln_stats) {
+                        const f32x4 ug = *(const f32x4*)(uw + wc + 32);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j + GJ][i][g * 4 + e] + gq[e]);
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_f(ln_fix(acc[j + GJ][i][g * 4 + e], ln_mean, ln_rstd, ug[e], gq[e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j + GJ][i][g * 4 + e] + gq[e]);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= a.scale;
                 // output channel inside the wave tile (GEGLU: value channels only, 32 per 64-row group)
                 const int oc = !GEGLU ? wc : (MS == 32 ? (j >> 1) * 32 + 8 * g + lq : (j >> 2) * 32 + (j & 1) * 16 + lq);
-                if (a.out_kind == OUT_F16) {
+                if (okind == OUT_F16) {
                     h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     *(h4*)(cst + prow * PITCH + oc * 2) = pk;
                 } else if (row < a.M && ocol0 + oc < nvalid) {
                     // direct paths (rare outputs): lane = pixel, 4 consecutive channels
                     const int ch = ocol0 + oc;
-                    if (a.out_kind == OUT_F32) {
+                    if (okind == OUT_F32) {
                         f32x4 pk = {v[0], v[1], v[2], v[3]};
-                        *(f32x4*)((float*)a.out + (size_t)row * a.ld_out + ch) = pk;
+                        *(f32x4*)((float*)outp + (size_t)row * ldo + ch) = pk;
                     } else {
                         const int b = row / rps, t = row - b * rps;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const size_t off = ((size_t)b * nvalid + ch + e) * a.ld_out + t;
-                            if (a.out_kind == OUT_F16_T) ((half_t*)a.out)[off] = (half_t)v[e];
-                            else ((float*)a.out)[off] = v[e];
+                            const size_t off = ((size_t)b * nvalid + ch + e) * ldo + t;
+                            if (okind == OUT_F16_T) ((half_t*)outp)[off] = (half_t)v[e];
+                            else ((float*)outp)[off] = v[e];
                         }
                     }
                 }
             }
         }
       }
-        if (a.out_kind == OUT_F16) {
+        if (okind == OUT_F16) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private tile: no barrier needed
             // ---- LDS -> (+ residual) -> 16-byte row-contiguous global stores; all loads first, then all stores
             h8 v[WB_IT], rr[WB_IT];
@@ -381,7 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 const int grow = m0 + wm * TM + ip * 32 + pr;
                 const int gcol = ocol0 + ck * 8;
                 ok[it] = c < 32 * CPR && grow < a.M && gcol < nvalid;
-                goff[it] = (size_t)grow * a.ld_out + gcol;
+                goff[it] = (size_t)grow * ldo + gcol;
                 if (ok[it]) {
                     const char* sp = cst + pr * PITCH + ck * 16;
                     const h4 lo = *(const h4*)sp, hi = *(const h4*)(sp + 8);
@@ -396,10 +449,42 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[it][e] = (half_t)((float)v[it][e] + (float)rr[it][e]);
                     }
-                    *(h8*)((half_t*)a.out + goff[it]) = v[it];
+                    *(h8*)((half_t*)outp + goff[it]) = v[it];
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
+            if constexpr (OUT_TN == 160) {
+            if (a.stats_out) {
+                // LayerNorm partial sums of the rows just written, from the STORED fp16 values: every lane contributes its
+                // 8 channels to (row, chunk) of a wave-private LDS table (the staging tile is dead by now); then one lane per
+                // row adds the row's CPR chunks in fixed order -> slot (n0 + wn * TN) / 160 of stats_out
+                float* tab = (float*)cst;                        // [32][CPR][2]
+#pragma unroll
+                for (int it = 0; it < WB_IT; ++it) {
+                    const int c = lane + it * 64;
+                    if (c < 32 * CPR) {
+                        float sm = 0.f, sq = 0.f;
+                        if (ok[it]) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = (float)v[it][e]; sm += f; sq += f * f; }
+                        }
+                        tab[2 * c] = sm; tab[2 * c + 1] = sq;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 32) {
+                    const int grow = m0 + wm * TM + ip * 32 + lane;
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int k = 0; k < CPR; ++k) { sm += tab[2 * (lane * CPR + k)]; sq += tab[2 * (lane * CPR + k) + 1]; }
+                    if (grow < a.M) {
+                        float* dst = a.stats_out + ((size_t)grow * (a.N / 160) + (n0 + wn * TN) / 160) * 2;
+                        dst[0] = sm; dst[1] = sq;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            }
         }
     }
     }   // !SPLIT
@@ -408,7 +493,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false, int MS = 16>
 int launch2(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
-    constexpr int smem = ring + (1 + RV_MAX) * BN * 4;      // + staged bias and emb rows
+    constexpr int smem = ring + (1 + RV_MAX) * BN * 4 + (2 * BM + BN) * 4;      // + staged bias, emb rows, LayerNorm (mean, rstd), u
     static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;

@@ -344,3 +344,34 @@ int layernorm_launch(const half_t* x, int rows, int C, const float* gamma, const
     else hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
+
+// LayerNorm partial sums of every token row, for a consumer GEMM that has the LayerNorm folded in (IgemmArgs::ln_stats),
+// when the producing GEMM could not emit them from its own epilogue (2-stage kernel, split-K).  SAME slots (160 columns
+// each; one slot when C is not a multiple of 160) and the SAME order of fp32 additions as the pipelined kernel's epilogue --
+// eight channels of a 16-byte chunk, then the slot's chunks in order -- so the statistics, and with them every output bit, do
+// not depend on which kernel produced them (a sample's result stays independent of the batch it is evaluated in).
+__global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict__ x, int rows, int C, int slots,
+                                                        float* __restrict__ stats) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * slots) return;
+    const size_t row = i / slots;
+    const int slot = (int)(i - row * slots), w = C / slots;
+    const half_t* p = x + row * C + (size_t)slot * w;
+    float sm = 0.f, sq = 0.f;
+    for (int k = 0; k < (w >> 3); ++k) {
+        const h8 v = *(const h8*)(p + (k << 3));
+        float cs = 0.f, cq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; cs += f; cq += f * f; }
+        sm += cs; sq += cq;
+    }
+    stats[i * 2] = sm; stats[i * 2 + 1] = sq;
+}
+int row_stats_slots(int C) { return (C % 160) == 0 ? C / 160 : 1; }
+int row_stats_launch(const half_t* x, int rows, int C, float* stats, hipStream_t s) {
+    if ((C & 7) || rows <= 0) return FGDM_ERR_ARG;
+    const int slots = row_stats_slots(C);
+    const size_t n = (size_t)rows * slots;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, rows, C, slots, stats);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}

@@ -193,12 +193,22 @@ int fgdm_op_conv2d(const void* x0, int C0, const void* x1, int C1, const float* 
                    int upsample, int act, float scale, void* out, void* stream);
 int fgdm_op_linear(const void* x, const float* w, const float* bias, const void* resid, int M, int K, int N,
                    int act, int out_kind, int rows_per_sample, int ld_out, void* out, void* stream);
+/* Producer / consumer pair of a transformer-block LayerNorm (ldm/modules/attention.py:234-240: attn(norm(x)), ff(norm(x))) as
+ * the engine evaluates it: h = x W1^T + b1 (+ resid) is written as fp16 [M, C] together with per-row partial sums, and
+ * y = act(LayerNorm(h; gamma, beta, eps 1e-5) W2^T + b2) runs on the RAW h with the LayerNorm folded into W2 and applied to
+ * the fp32 accumulator (no normalised copy of h exists).  x fp16 [M, K1], resid fp16 [M, C] or NULL, weights fp32 in the
+ * reference's [out, in] layout, act2 0 or 3 (GEGLU: y is [M, N2 / 2]).  *slots_used: partial-sum slots per row. */
+int fgdm_op_linear_ln_linear(const void* x, const float* w1, const float* b1, const void* resid, const float* gamma,
+                             const float* beta, const float* w2, const float* b2, int M, int K1, int C, int N2, int act2,
+                             void* h_out, void* y_out, int* slots_used, void* stream);
 /* Tuning aids: force the implicit-GEMM tile configuration process-wide (0 = automatic; 1-3 = 2-stage kernel
  * 128x128 / 128x64 / 64x64; 4-6 = pipelined kernel 256x320 / 256x256 / 128x320), and time one conv / linear shape on
  * random data (average device milliseconds over `iters` launches). */
 int fgdm_debug_force_igemm_cfg(int cfg);
 int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample, int act,
                      int use_resid, int cfg, int iters, float* avg_ms);
+/* ... one attention shape (softmax(QK^T d^-1/2) V over B x heads, T queries, Tk keys) ... */
+int fgdm_bench_attention(int B, int heads, int T, int Tk, int d, int iters, float* avg_ms);
 /* ... and one GroupNorm32(+SiLU) (kind 0, optional virtual concat C1) or LayerNorm (kind 1) shape. */
 int fgdm_bench_norm(int kind, int B, int HW, int C0, int C1, int silu, int iters, float* avg_ms);
 int fgdm_op_groupnorm(const void* x0, int C0, const void* x1, int C1, int B, int HW, const float* gamma,

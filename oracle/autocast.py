@@ -44,6 +44,8 @@ _LOWER = {
     torch.addmm, T.addmm, torch.baddbmm, T.baddbmm, torch.addbmm, torch.einsum, torch.prelu, F.prelu,
     F.scaled_dot_product_attention,
 }
+# ops whose argument 1 is a parameter (cached cast)
+_WEIGHTED = {torch.conv1d, torch.conv2d, torch.conv3d, F.conv1d, F.conv2d, F.conv3d, F.linear, torch._C._nn.linear}
 _FP32 = {
     F.group_norm, torch.group_norm, F.layer_norm, torch.layer_norm, torch.native_layer_norm,
     torch.exp, T.exp, torch.expm1, torch.log, T.log, torch.log2, torch.log10, torch.log1p,
@@ -94,14 +96,12 @@ class Emulation(TorchFunctionMode):
         self.enabled = True
         self.stats = {'lower': 0, 'fp32': 0, 'promote': 0}
 
-    def _grid16(self, t):
-        """fp32 tensor whose values lie on the fp16 grid (the cast autocast performs), cached for big leaves
-        such as weights exactly like autocast's own weight-cast cache."""
+    def _grid16(self, t, weight=False):
+        """fp32 tensor whose values lie on the fp16 grid (the cast autocast performs).  WEIGHTS (argument 1 of conv / linear)
+        are cached like autocast's own weight-cast cache; activations never are (a cache entry keeps its tensor alive)."""
         if t.dtype == torch.float16:
             return t.float()
-        if t.dtype != torch.float32:
-            return t.half().float()
-        if t.numel() < 4096:
+        if not weight or t.dtype != torch.float32 or t.numel() < 4096:
             return t.half().float()
         key = (t.data_ptr(), t.numel(), t._version)
         hit = self._wcache.get(key)
@@ -117,6 +117,8 @@ class Emulation(TorchFunctionMode):
         if func in _LOWER:
             self.stats['lower'] += 1
             f = lambda t: self._grid16(t) if t.is_floating_point() else t
+            if func in _WEIGHTED and len(args) >= 2 and isinstance(args[1], torch.Tensor) and args[1].is_floating_point():
+                args = (args[0], self._grid16(args[1], weight=True)) + tuple(args[2:])
             out = func(*_map(args, f), **_map(kwargs, f))
             return _map(out, lambda t: t.half() if t.is_floating_point() else t)
         if func in _FP32:

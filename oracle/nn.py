@@ -92,7 +92,7 @@ def attention(p, pre, x, ctx, heads, fp32_sim=False):
     c = p[pre + 'to_q.weight'].shape[0]
     d = c // heads
     if P.MODE == 'engine':
-        return _attention_engine(p, pre, x, ctx, heads, d)
+        raise RuntimeError("'engine' mode folds the LayerNorm into the projections: go through transformer_block")
     q = _lin(x, p, pre + 'to_q', bias=False)
     k = _lin(ctx, p, pre + 'to_k', bias=False)
     v = _lin(ctx, p, pre + 'to_v', bias=False)
@@ -112,14 +112,37 @@ def attention(p, pre, x, ctx, heads, fp32_sim=False):
     return _lin(o, p, pre + 'to_out.0')
 
 
-def _attention_engine(p, pre, x, ctx, heads, d):
-    """The engine's attention numerics (fgdm_amd/csrc/attention.hip): log2(e) d^-1/2 folded into the packed to_q
-    weights, fp32 scores in the log2 domain, fp16 probabilities, normaliser = sum of the fp16 probabilities where the
-    padded PV tile has a spare row (d = 40, 80), of the fp32 ones otherwise (d = 160)."""
+def _ln_lin(p, x, ln, lin, bias=True, wscale=None):
+    """'engine' mode: a LayerNorm folded into the Linear it feeds (fgdm_amd/csrc/common.h IgemmArgs::ln_stats).  The packed
+    weights are fp16(gamma_k W_nk [* wscale]), the bias picks up sum_k beta_k W_nk, and the GEMM runs on the RAW fp16 row with
+    (mean, rstd) applied to the fp32 accumulator: rstd (x W'^T - mean sum_k W') + c == Linear'(normalise(x)) with the normalised
+    row never rounded or stored."""
+    key = ('ln', ln, lin, wscale)
+    hit = P._wcache.get(key)
+    if hit is None:
+        W = p[lin + '.weight'] if wscale is None else p[lin + '.weight'] * wscale
+        c = W @ p[ln + '.bias']
+        if bias:
+            c = c + p[lin + '.bias']
+        hit = ((W * p[ln + '.weight'][None, :]).half().float(), c)
+        P._wcache[key] = hit
+    xn = F.layer_norm(x, x.shape[-1:], None, None, 1e-5)
+    return F.linear(xn, hit[0], hit[1])
+
+
+def _attention_engine(p, pre, x, ctx, heads, d, ln):
+    """The engine's attention numerics (fgdm_amd/csrc/attention.hip): x is the RAW token matrix, `ln` the LayerNorm that is
+    folded into to_q (and, for self-attention, to_k / to_v); log2(e) d^-1/2 folded into the packed to_q weights; fp32 scores
+    in the log2 domain, fp16 probabilities, normaliser = sum of the fp16 probabilities where the padded PV tile has a spare
+    row (d = 40, 80), of the fp32 ones otherwise (d = 160)."""
     import math
-    q = st(_lin(x, p, pre + 'to_q', bias=False, wscale=math.log2(math.e) * d ** -0.5))
-    k = st(_lin(ctx, p, pre + 'to_k', bias=False))
-    v = st(_lin(ctx, p, pre + 'to_v', bias=False))
+    q = st(_ln_lin(p, x, ln, pre + 'to_q', bias=False, wscale=math.log2(math.e) * d ** -0.5))
+    if ctx is None:
+        k = st(_ln_lin(p, x, ln, pre + 'to_k', bias=False))
+        v = st(_ln_lin(p, x, ln, pre + 'to_v', bias=False))
+    else:
+        k = st(_lin(ctx, p, pre + 'to_k', bias=False))
+        v = st(_lin(ctx, p, pre + 'to_v', bias=False))
     b, n, c = q.shape
 
     def split(t):
@@ -136,6 +159,12 @@ def _attention_engine(p, pre, x, ctx, heads, d):
 
 def transformer_block(p, pre, x, ctx, heads, fp32_sim=False):
     # attention.py:234-240
+    if P.MODE == 'engine':      # norm1 / norm2 / norm3 live inside the GEMMs they feed
+        d = x.shape[-1] // heads
+        x = st(st(_attention_engine(p, pre + 'attn1.', x, None, heads, d, pre + 'norm1')) + x)
+        x = st(st(_attention_engine(p, pre + 'attn2.', x, ctx, heads, d, pre + 'norm2')) + x)
+        a, g = _ln_lin(p, x, pre + 'norm3', pre + 'ff.net.0.proj').chunk(2, dim=-1)
+        return st(st(_lin(st(a * F.gelu(g)), p, pre + 'ff.net.2')) + x)
     x = st(st(attention(p, pre + 'attn1.', _ln(x, p, pre + 'norm1'), None, heads, fp32_sim)) + x)
     x = st(st(attention(p, pre + 'attn2.', _ln(x, p, pre + 'norm2'), ctx, heads, fp32_sim)) + x)
     h = _ln(x, p, pre + 'norm3')

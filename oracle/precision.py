@@ -11,7 +11,11 @@
                 * a GEMM's fused epilogue -- bias, timestep-embedding row, SiLU / ReLU / GEGLU, ControlNet scale --
                   is evaluated in fp32 on the accumulator and the result is rounded ONCE to fp16;
                 * a residual / skip / adapter-feature add reads two fp16 tensors, adds in fp32 and rounds to fp16;
-                * GroupNorm(+SiLU) and LayerNorm: fp32 statistics and affine, one rounding to fp16 at the end;
+                * GroupNorm(+SiLU): fp32 statistics and affine, one rounding to fp16 at the end;
+                * the three LayerNorms of a transformer block are FOLDED into the Linears they feed (to_q/to_k/to_v, attn2.to_q,
+                  ff.net.0.proj): weights fp16(gamma_k W_nk), bias + sum_k beta_k W_nk, the GEMM runs on the raw fp16 tokens and
+                  (mean, rstd) -- fp32 sums of the stored tokens -- are applied to the fp32 accumulator; the normalised tokens
+                  are never rounded or stored (CLIP's LayerNorms stay separate kernels: fp32 statistics, one rounding);
                 * attention: log2(e) d^-1/2 is folded into the to_q weights before their fp16 rounding; scores and the
                   running max stay fp32; probabilities are rounded to fp16 for the PV product, the normaliser is the
                   sum of those fp16 probabilities (head dims with a spare MFMA row: 40, 80) or of the fp32 ones (160);

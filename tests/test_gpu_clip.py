@@ -1,6 +1,6 @@
 """Text encoder parity through the C ABI (fgdm_clip_encode): HIP engine vs transformers.CLIPTextModel with the same
 synthetic weights (tests/golden/clip.npz; clip_ac.npz = the same model under the reference's autocast policy) and vs the
-CPU oracle.  Tolerance max(1e-3, 1.25 x floor), floor = |autocast golden - fp32 golden| (tests/common.py: check_net)."""
+CPU oracle.  Tolerance max(1e-3, 1.1 x floor), floor = |autocast golden - fp32 golden| (tests/common.py: check_net)."""
 import pytest
 import torch
 

@@ -35,7 +35,7 @@ def test_txt2img_fgdm_inference_call_sequence():
     model.eval()
     model.tokenizer = _tokenizer
     try:
-        n_samples, H, W, C, f, scale, steps = 2, 256, 256, 4, 8, 7.5, 3
+        n_samples, H, W, C, f, scale, steps = 2, 256, 256, 4, 8, 7.5, 4     # (S = 3 fails in the reference too: timestep 1000)
         for sampler in (DDIMSampler(model), PLMSSampler(model)):            # :182-185
             with torch.no_grad():
                 with model.ema_scope():
@@ -84,7 +84,7 @@ def test_seg2image_inference_call_sequence():
         seg = (synth.hint(1, 256, seed=91)[0].transpose(1, 2, 0) * 255).astype(np.uint8)      # a 256x256 "segmentation map"
         inp = np.zeros((300, 300, 3), np.uint8)                 # input_image only fixes the working resolution (:45-47)
         x_T = torch.from_numpy(synth.latents(2, 32, 32, seed=92)).cuda()
-        res = s2i.process(inp, 'a bedroom', 'best quality, extremely detailed', 'lowres, bad anatomy', 2, 256, 256, 3, False, 1.0,
+        res = s2i.process(inp, 'a bedroom', 'best quality, extremely detailed', 'lowres, bad anatomy', 2, 256, 256, 4, False, 1.0,
                           9.0, 12345, 0.0, spath=seg, x_T=x_T)
         assert len(res) == 3 and all(r.dtype == np.uint8 and r.shape == (256, 256, 3) for r in res)
         assert np.array_equal(res[0], seg)                      # [detected_map] + results

@@ -1,7 +1,7 @@
 """Whole-network parity through the C ABI: HIP engine vs golden vectors from the imported reference
 (tests/golden: fp32 CPU, and the same modules under the reference's CUDA-autocast policy) and vs the CPU oracle.
 
-Tolerance for one complete UNet / ControlNet evaluation: max(1e-3, 1.25 x floor), floor = the measured distance of the
+Tolerance for one complete UNet / ControlNet evaluation: max(1e-3, 1.1 x floor), floor = the measured distance of the
 reference's own autocast (GPU) numerics from its fp32 (CPU) path on the same inputs -- see tests/common.py: check_net.
 Per-kernel (test_gpu_ops.py) and per-block (test_gpu_blocks.py) tests hold the flat 1e-3 bar."""
 import numpy as np

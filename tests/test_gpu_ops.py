@@ -326,3 +326,76 @@ def test_attention_logit_ranges_d40(lib, gain, shift):
     assert lib.fgdm_op_attention(_p(qd), Cc, _p(kd), Cc, _p(vtd), Tk, _p(out), Cc, B, Hh, T, Tk, d, _st()) == 0
     assert torch.isfinite(out).all()
     assert relerr(out.float().cpu(), ref) < 2 * TOL, float(sim.abs().max())
+
+
+# M, K1, C, N2, act2 (0 / 3 = GEGLU), resid, forced tile cfg (0 = automatic), expected partial-sum slots per row (< 0: from
+# the separate row-statistics pass instead of the producing GEMM's epilogue)
+LN_CASES = [
+    (16384, 320, 320, 640, 0, True, 0, 2),      # 128x320 pipelined tiles: statistics from the producer's epilogue (2 slots)
+    (65536, 320, 320, 2560, 3, True, 0, 2),     # 256x320 producer, GEGLU consumer on 256x256 tiles
+    (8192, 1280, 1280, 1280, 0, True, 0, 8),    # 8 slots per row
+    (8192, 640, 640, 5120, 3, False, 0, 4),
+    (200, 320, 320, 320, 0, True, 0, -2),       # small problem: 2-stage kernel + the separate row-statistics pass (same 2 slots)
+    (16384, 320, 320, 640, 0, True, 1, -2),     # the same shape as case 0 forced onto the 2-stage kernel
+    (4100, 640, 640, 640, 0, False, 6, 4),      # ragged M on the 128x320 tiles
+]
+
+
+@pytest.mark.parametrize('case', LN_CASES, ids=lambda c: f'M{c[0]}_K{c[1]}_C{c[2]}_N{c[3]}_act{c[4]}_cfg{c[6]}')
+def test_layernorm_folded_into_consumer_gemm(lib, case):
+    """The transformer block's LayerNorms (attention.py:234-240) never run as kernels: the producing GEMM leaves per-row partial
+    sums next to its output, the consuming GEMM multiplies the raw tokens with gamma-folded weights and applies (mean, rstd)
+    to its fp32 accumulator.  Reference arithmetic: fp16 h as stored, then nn.LayerNorm + nn.Linear (+ GEGLU) in fp32 on the
+    fp16-rounded folded weights."""
+    M, K1, Cc, N2, act2, use_res, cfg, want_slots = case
+    x = rnd((M, K1), 1).half()
+    w1, b1 = rnd((Cc, K1), 2, K1 ** -0.5), rnd((Cc,), 3, 0.1)
+    res = rnd((M, Cc), 4).half() if use_res else None
+    gamma, beta = 1.0 + 0.2 * rnd((Cc,), 5), 0.1 * rnd((Cc,), 6) + 0.05
+    w2, b2 = rnd((N2, Cc), 7, Cc ** -0.5), rnd((N2,), 8, 0.1)
+    nout = N2 // 2 if act2 == 3 else N2
+    h = torch.empty(M, Cc, dtype=torch.float16, device='cuda')
+    y = torch.empty(M, nout, dtype=torch.float16, device='cuda')
+    slots = C.c_int(0)
+    dev = lambda t: None if t is None else t.cuda()
+    xs, rs, ws = dev(x), dev(res), [dev(t) for t in (w1, b1, gamma, beta, w2, b2)]
+    try:
+        lib.fgdm_debug_force_igemm_cfg(cfg)
+        rc = lib.fgdm_op_linear_ln_linear(_p(xs), _p(ws[0]), _p(ws[1]), _p(rs), _p(ws[2]), _p(ws[3]), _p(ws[4]), _p(ws[5]), M, K1, Cc,
+                                          N2, act2, _p(h), _p(y), C.byref(slots), _st())
+    finally:
+        lib.fgdm_debug_force_igemm_cfg(0)
+    assert rc == 0
+    assert slots.value == want_slots
+    # producer: fp16 GEMM result, then the fp16 residual added and rounded (the engine's policy)
+    h_ref = h16(F.linear(x.float(), h16(w1), b1))
+    if use_res:
+        h_ref = h16(h_ref + res.float())
+    assert relerr(h.float().cpu(), h_ref) < TOL
+    # consumer on the engine's OWN h (so that only the folded LayerNorm + GEMM is judged)
+    hh = h.float().cpu()
+    wf = h16(w2 * gamma[None, :])
+    cb = w2 @ beta + b2
+    z = F.linear(F.layer_norm(hh, (Cc,), None, None, 1e-5), wf, cb)
+    if act2 == 3:
+        a, g = z.chunk(2, dim=-1)
+        z = a * F.gelu(g)
+    assert relerr(y.float().cpu(), h16(z)) < TOL
+    if cfg == 0:      # the same problem forced onto the 2-stage kernels (+ the separate statistics pass): not a bit may differ --
+        h2 = torch.empty_like(h)           # which kernel evaluates a layer depends on the batch size, a sample's result must not
+        y2 = torch.empty_like(y)
+        try:
+            lib.fgdm_debug_force_igemm_cfg(1)
+            assert lib.fgdm_op_linear_ln_linear(_p(xs), _p(ws[0]), _p(ws[1]), _p(rs), _p(ws[2]), _p(ws[3]), _p(ws[4]), _p(ws[5]), M,
+                                                K1, Cc, N2, act2, _p(h2), _p(y2), C.byref(slots), _st()) == 0
+        finally:
+            lib.fgdm_debug_force_igemm_cfg(0)
+        assert slots.value == -abs(want_slots)
+        assert torch.equal(h2, h), 'producer output differs between kernels'
+        assert torch.equal(y2, y), 'LayerNorm-folded consumer output differs between kernels'
+    # ... which is the reference's LayerNorm -> Linear up to the fp16 rounding of the weights
+    z32 = F.linear(F.layer_norm(hh, (Cc,), gamma, beta, 1e-5), w2, b2)
+    if act2 == 3:
+        a, g = z32.chunk(2, dim=-1)
+        z32 = a * F.gelu(g)
+    assert relerr(y.float().cpu(), z32) < TOL
