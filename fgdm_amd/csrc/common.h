@@ -97,14 +97,18 @@ int nhwc_f16_to_nchw_f32(const half_t* x, float* y, int B, int C, int HW, hipStr
 int im2col3x3(const half_t* x, half_t* A, int B, int H, int W, int C, int stride, int Kpad, hipStream_t s);
 int avgpool2(const half_t* x, half_t* y, int B, int H, int W, int C, hipStream_t s);
 int add_f16(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s);
+int add_f16_to_f32(const float* a, const half_t* b, float* y, size_t n, hipStream_t s);   // y = a + float(b): fp32 residual stream
 int timestep_embed(const int64_t* t, const float* t_float, half_t* y, int B, int dim, int rows_pad, hipStream_t s);
 int vae_prequant(const float* z, const float* wb, float scale, half_t* y, int B, int HW, hipStream_t s);
 int softmax_rows(const float* S, half_t* P, int rows, int cols, hipStream_t s);
 int image_to_u8(const float* x, uint8_t* y, int B, int C, int HW, int mode, hipStream_t s);
 int resize_linear_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int u8_to_hint(const uint8_t* src, float* dst, int B, int HW, int C, hipStream_t s);
-int embed_tokens(const int64_t* ids, const half_t* tok, const half_t* pos, half_t* out, int rows, int T, int W, int vocab,
+int embed_tokens(const int64_t* ids, const float* tok, const float* pos, float* out, int rows, int T, int W, int vocab,
                  hipStream_t s);
+// LayerNorm of an fp32 matrix -> fp16 (out16) or fp32 (out32), exactly one of them non-null
+int layernorm32_launch(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, half_t* out16,
+                       float* out32, hipStream_t s);
 int f16_to_f32(const half_t* x, float* y, size_t n, hipStream_t s);
 // causal / full attention over short sequences (T <= 128, d = 64) with q|k|v as column blocks of one matrix
 int small_attention_launch(const half_t* qkv, int ld, int koff, int voff, half_t* out, int ldo, int B, int heads, int T,

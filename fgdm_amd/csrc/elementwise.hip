@@ -138,6 +138,15 @@ int add_f16(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s
 }
 
 // y[b] = [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half)   (util.py:160-180); rows >= B are zero
+// y = a + float(b): a fp16 branch output added to the fp32 residual stream (CLIP's hidden states under autocast promote)
+__global__ void k_add_f16_to_f32(const float* __restrict__ a, const half_t* __restrict__ b, float* __restrict__ y, size_t n) {
+    EW_LOOP(i, n) y[i] = a[i] + (float)b[i];
+}
+int add_f16_to_f32(const float* a, const half_t* b, float* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_f16_to_f32, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, b, y, n);
+    return LAUNCH_OK();
+}
+
 __global__ void k_timestep_embed(const int64_t* __restrict__ t, const float* __restrict__ tf, half_t* __restrict__ y,
                                  int B, int dim, int rows_pad) {
     const int half = dim / 2;

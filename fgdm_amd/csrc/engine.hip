@@ -168,8 +168,8 @@ struct ClipLayer { std::string pre; NormW ln1, ln2; GemmW qkv, o, fc1, fc2; };
 struct Clip {
     bool on = false, packed = false;
     std::string prefix;
-    half_t* tok = nullptr;    // [vocab][W] fp16
-    half_t* pos = nullptr;    // [max_len][W] fp16
+    float* tok = nullptr;     // [vocab][W] fp32 (nn.Embedding is not an autocast op: the residual stream starts in fp32)
+    float* pos = nullptr;     // [max_len][W] fp32
     std::vector<ClipLayer> layers;
     NormW final_ln;
 };
@@ -805,16 +805,14 @@ struct fgdm_engine {
 
     int pack_clip() {
         Clip& c = clip;
-        auto up16 = [&](const std::string& name, half_t** dst) -> int {
+        auto up32 = [&](const std::string& name, float** dst) -> int {
             const ParamSlot* w = slot(name);
             if (!w) return FGDM_ERR_STATE;
-            std::vector<half_t> h(w->host.size());
-            for (size_t i = 0; i < h.size(); ++i) h[i] = (half_t)w->host[i];
-            *dst = upload(h);
+            *dst = upload(w->host);
             return *dst ? FGDM_OK : fail(FGDM_ERR_NOMEM, "hipMalloc failed");
         };
-        CHK(up16(c.prefix + "embeddings.token_embedding.weight", &c.tok));
-        CHK(up16(c.prefix + "embeddings.position_embedding.weight", &c.pos));
+        CHK(up32(c.prefix + "embeddings.token_embedding.weight", &c.tok));
+        CHK(up32(c.prefix + "embeddings.position_embedding.weight", &c.pos));
         for (ClipLayer& l : c.layers) {
             CHK(pack_norm(l.ln1, l.pre + "layer_norm1"));
             CHK(pack_norm(l.ln2, l.pre + "layer_norm2"));
@@ -1580,11 +1578,20 @@ struct fgdm_engine {
         if (!clip.packed) return fail(FGDM_ERR_STATE, "weights not finalized");
         if (B <= 0 || T <= 0 || T > cfg.clip_max_len) return fail(FGDM_ERR_ARG, "bad shape (T must be <= clip_max_len)");
         const int W = cfg.clip_width, rows = B * T;
-        Tensor h = talloc(1, 1, rows, W), n, qkv, a, h2, f;
-        if (!h.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        if (embed_tokens(ids, clip.tok, clip.pos, h.p, rows, T, W, cfg.clip_vocab, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "embedding kernel");
+        // the hidden states are an fp32 residual stream, as under the reference's autocast: fp32 embeddings, every branch
+        // (attention / MLP output, a fp16 GEMM result) is promoted when added to it, LayerNorm reads fp32
+        Tensor n, qkv, a, f;
+        float* h = (float*)arena.alloc((size_t)rows * W * sizeof(float));
+        float* h2 = (float*)arena.alloc((size_t)rows * W * sizeof(float));
+        if (!h || !h2) return fail(FGDM_ERR_NOMEM, "workspace");
+        if (embed_tokens(ids, clip.tok, clip.pos, h, rows, T, W, cfg.clip_vocab, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "embedding kernel");
+        auto ln32 = [&](const NormW& nw, const float* src, Tensor* dst) -> int {
+            *dst = talloc(1, 1, rows, W);
+            if (!dst->p) return fail(FGDM_ERR_NOMEM, "workspace");
+            return layernorm32_launch(src, rows, W, nw.g, nw.b, 1e-5f, dst->p, nullptr, s) == FGDM_OK ? FGDM_OK : fail(FGDM_ERR_HIP, "layernorm");
+        };
         for (const ClipLayer& l : clip.layers) {
-            CHK(lnorm(l.ln1, h, &n));
+            CHK(ln32(l.ln1, h, &n));
             CHK(linear(l.qkv, n, Epi{}, &qkv));
             tfree(n);
             a = talloc(1, 1, rows, W);
@@ -1592,18 +1599,22 @@ struct fgdm_engine {
             if (small_attention_launch(qkv.p, 3 * W, W, 2 * W, a.p, W, B, cfg.clip_heads, T, W / cfg.clip_heads, 1, s) != FGDM_OK)
                 return fail(FGDM_ERR_HIP, "text attention kernel");
             tfree(qkv);
-            { Epi e; e.resid = h.p; e.ld_res = W; CHK(linear(l.o, a, e, &h2)); }
-            tfree(a); tfree(h);
-            CHK(lnorm(l.ln2, h2, &n));
+            Tensor br;
+            CHK(linear(l.o, a, Epi{}, &br));                 // branch output fp16, as autocast leaves it
+            tfree(a);
+            if (add_f16_to_f32(h, br.p, h2, br.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
+            tfree(br);
+            CHK(ln32(l.ln2, h2, &n));
             { Epi e; e.act = ACT_QGELU; CHK(linear(l.fc1, n, e, &f)); }
             tfree(n);
-            { Epi e; e.resid = h2.p; e.ld_res = W; CHK(linear(l.fc2, f, e, &h)); }
-            tfree(f); tfree(h2);
+            CHK(linear(l.fc2, f, Epi{}, &br));
+            tfree(f);
+            if (add_f16_to_f32(h2, br.p, h, br.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "add kernel");
+            tfree(br);
         }
-        CHK(lnorm(clip.final_ln, h, &n));
-        tfree(h);
-        if (f16_to_f32(n.p, out, n.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "convert kernel");
-        tfree(n);
+        // final_layer_norm: fp32 in, fp32 out -- straight into the caller's buffer
+        if (layernorm32_launch(h, rows, W, clip.final_ln.g, clip.final_ln.b, 1e-5f, nullptr, out, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layernorm");
+        arena.release(h); arena.release(h2);
         return FGDM_OK;
     }
 

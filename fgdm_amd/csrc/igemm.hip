@@ -332,7 +332,10 @@ void igemm_set_force_cfg(int cfg) { g_force_cfg = cfg; }
 // tile configuration for `a` (0 = the 2-stage kernel picks one of its own tiles; 4..9 = pipelined kernel cfg 0..5)
 static int pick_force(const IgemmArgs& a) {
     int force = a.force_cfg ? a.force_cfg : g_force_cfg;
-    if (a.act == ACT_QGELU && force >= 4) force = 0;   // the pipelined kernel's epilogue does not carry quick-GELU
+    if (a.act == ACT_QGELU) {                   // the pipelined kernel's epilogue does not carry quick-GELU (text encoder only)
+        if (force >= 4) force = 0;
+        if (force == 0) return 0;
+    }
     if (force == 0) {
         const bool geglu = a.act == ACT_GEGLU;
         if (!geglu && a.N % 320 == 0) {

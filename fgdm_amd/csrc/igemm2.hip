@@ -65,7 +65,10 @@ constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (m
 // v_mfma_f32_32x32x16_f16 (two k-substeps per 32x32 tile).  Same flops, same LDS bytes, same accumulator registers; the
 // chip holds a higher clock under the 16x16x32 shape (this kernel is power-limited: all-zero operands run 1.3x faster
 // than random ones), measured +3..9 % on the conv shapes (tools/bench_igemm.py cfg 4 vs 7).
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS>
+// LN: the consumer side of a folded LayerNorm (IgemmArgs::ln_stats) is its own instantiation: the (mean, rstd, u) fix-up in the
+// register stage does not fit next to the 160 accumulator registers of the 256x320 tile (208 bytes of scratch per lane when
+// it was a run-time branch there), so LN consumers use the 128x320 / 256x256 tiles and every other layer pays nothing
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN>
 __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, T = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     const int nsmp = a.rowvec ? last_row / rps - smp0 + 1 : 0;
     const bool rv_in_lds = nsmp <= RV_MAX;
     for (int c = tid; c < BN; c += T) bias_l[c] = a.bias ? a.bias[n0 + c] : 0.f;
-    if (a.ln_stats) {
+    if constexpr (LN) {
         for (int c = tid; c < BN; c += T) u_l[c] = a.ln_u[n0 + c];
         for (int r = tid; r < BM; r += T) {      // partial sums in fixed slot order; E[x^2] - mean^2 in double
             float mean = 0.f, rstd = 0.f;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         const int bsmp = (a.rowvec && row < a.M) ? row / rps : smp0;
         const float* rw = rv_l + (bsmp - smp0) * BN + wn * TN;
         const int trow = wm * TM + ip * 32 + prow;           // row inside the tile
-        const float ln_mean = a.ln_stats ? mr_l[2 * trow] : 0.f, ln_rstd = a.ln_stats ? mr_l[2 * trow + 1] : 1.f;
+        const float ln_mean = LN ? mr_l[2 * trow] : 0.f, ln_rstd = LN ? mr_l[2 * trow + 1] : 1.f;
         const float* uw = u_l + wn * TN;
         // ---- registers -> (bias, emb, activation, scale) -> fp16 -> LDS [pixel][channel]
 #pragma unroll
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 const int wc = j * MS + (MS == 32 ? 8 * g : 0) + lq;      // packed channel inside the wave tile
                 const f32x4 bq = *(const f32x4*)(bw + wc);
                 float v[4];
-                if (a.ln_stats) {
+                if constexpr (LN) {
                     const f32x4 uq = *(const f32x4*)(uw + wc);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ln_fix(acc[j][i][g * 4 + e], ln_mean, ln_rstd, uq[e], bq[e]);
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 if constexpr (GEGLU) {      // packed rows: 64-row groups [32 value | 32 gate]
                     constexpr int GJ = MS == 32 ? 1 : 2;                 // gate tile = value tile + GJ
                     const f32x4 gq = *(const f32x4*)(bw + wc + 32);
-                    if (a.ln_stats) {
+                    if constexpr (LN) {
                         const f32x4 ug = *(const f32x4*)(uw + wc + 32);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= gelu_f(ln_fix(acc[j + GJ][i][g * 4 + e], ln_mean, ln_rstd, ug[e], gq[e]));
@@ -442,6 +445,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                     if (a.resid) rr[it] = *(const h8*)(a.resid + (size_t)grow * a.ld_res + gcol);
                 }
             }
+            bool want_stats = false;
+            if constexpr (OUT_TN == 160) want_stats = a.stats_out != nullptr;
+            float* tab = (float*)cst;                            // [32][CPR][2], over the (by then dead) staging tile
+            if (want_stats) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every staging read has landed
 #pragma unroll
             for (int it = 0; it < WB_IT; ++it) {
                 if (ok[it]) {
@@ -451,16 +458,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                     }
                     *(h8*)((half_t*)outp + goff[it]) = v[it];
                 }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
-            if constexpr (OUT_TN == 160) {
-            if (a.stats_out) {
-                // LayerNorm partial sums of the rows just written, from the STORED fp16 values: every lane contributes its
-                // 8 channels to (row, chunk) of a wave-private LDS table (the staging tile is dead by now); then one lane per
-                // row adds the row's CPR chunks in fixed order -> slot (n0 + wn * TN) / 160 of stats_out
-                float* tab = (float*)cst;                        // [32][CPR][2]
-#pragma unroll
-                for (int it = 0; it < WB_IT; ++it) {
+                if (want_stats) {
+                    // LayerNorm partial sums of the rows just written, from the STORED fp16 values: this lane's 8 channels
+                    // -> (row, chunk) of a wave-private LDS table, right here so that v[it] dies with its store
                     const int c = lane + it * 64;
                     if (c < 32 * CPR) {
                         float sm = 0.f, sq = 0.f;
@@ -471,7 +471,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                         tab[2 * c] = sm; tab[2 * c + 1] = sq;
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
+            if (want_stats) {
+                // one lane per row adds the row's CPR chunks in fixed order -> slot (n0 + wn * TN) / 160 of stats_out
                 if (lane < 32) {
                     const int grow = m0 + wm * TM + ip * 32 + lane;
                     float sm = 0.f, sq = 0.f;
@@ -484,20 +487,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            }
         }
     }
     }   // !SPLIT
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false, int MS = 16>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false, int MS = 16, bool LN = false>
 int launch2(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4 + (2 * BM + BN) * 4;      // + staged bias, emb rows, LayerNorm (mean, rstd), u
     static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS>;
+    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -510,6 +512,11 @@ template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU, int MS = 16>
 int launch2m(const IgemmArgs& a, hipStream_t s) {
     return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS>(a, s)
                                : launch2<BM, BN, WM, WN, STAGES, true, GEGLU, false, MS>(a, s);
+}
+// consumer of a folded LayerNorm: always a LINEAR GEMM
+template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU, int MS = 16>
+int launch2ln(const IgemmArgs& a, hipStream_t s) {
+    return launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS, true>(a, s);
 }
 
 // out[m][n] = ((sum_s ws[s][m][n]) + bias + emb -> act) * scale + resid, fixed summation order
@@ -566,6 +573,16 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     const bool g = a.act == ACT_GEGLU;
     if (g && bn != 256) return FGDM_ERR_ARG;
     if (a.splitk > 1 && cfg != 2) return FGDM_ERR_ARG;
+    if (a.ln_stats) {       // LayerNorm consumers: the LN instantiations (128x320 in place of 256x320, see igemm2_kernel)
+        if (a.mode != IG_LINEAR || a.splitk > 1) return FGDM_ERR_ARG;
+        switch (cfg) {
+            case 0: case 2: return launch2ln<128, 320, 4, 2, 4, false>(a, s);
+            case 1: return g ? launch2ln<256, 256, 4, 2, 4, true>(a, s) : launch2ln<256, 256, 4, 2, 4, false>(a, s);
+            case 3: case 5: return launch2ln<128, 320, 4, 2, 4, false, 32>(a, s);
+            case 4: return g ? launch2ln<256, 256, 4, 2, 4, true, 32>(a, s) : launch2ln<256, 256, 4, 2, 4, false, 32>(a, s);
+            default: return FGDM_ERR_ARG;
+        }
+    }
     switch (cfg) {
         case 0: return launch2m<256, 320, 4, 2, 4, false>(a, s);
         case 1: return g ? launch2m<256, 256, 4, 2, 4, true>(a, s) : launch2m<256, 256, 4, 2, 4, false>(a, s);

@@ -345,6 +345,44 @@ int layernorm_launch(const half_t* x, int rows, int C, const float* gamma, const
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
+// LayerNorm over an fp32 token matrix (CLIP's fp32 residual stream): one wave per row, fp32 statistics; the result is stored
+// as fp16 (it feeds a GEMM: autocast rounds it there) or as fp32 (final_layer_norm: the encoder's output)
+template <typename OUT>
+__global__ __launch_bounds__(256) void ln32_kernel(const float* __restrict__ x, int rows, int C, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, OUT* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float sum = 0.f;
+    for (int c = lane * 4; c < C; c += 256) { const f32x4 v = *(const f32x4*)(xr + c); sum += v[0] + v[1] + v[2] + v[3]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; sq += d * d; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(size_t)row * C + c + e] = (OUT)((v[e] - mean) * rstd * gamma[c + e] + beta[c + e]);
+    }
+}
+int layernorm32_launch(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, half_t* out16,
+                       float* out32, hipStream_t s) {
+    if ((C & 3) || rows <= 0 || (!out16 == !out32)) return FGDM_ERR_ARG;
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (out16) hipLaunchKernelGGL(ln32_kernel<half_t>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out16);
+    else hipLaunchKernelGGL(ln32_kernel<float>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out32);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}
+
 // LayerNorm partial sums of every token row, for a consumer GEMM that has the LayerNorm folded in (IgemmArgs::ln_stats),
 // when the producing GEMM could not emit them from its own epilogue (2-stage kernel, split-K).  SAME slots (160 columns
 // each; one slot when C is not a multiple of 160) and the SAME order of fp32 additions as the pipelined kernel's epilogue --

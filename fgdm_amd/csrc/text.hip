@@ -4,28 +4,27 @@
 // LDS-resident VALU kernel (one workgroup per (head, prompt)); the projections and the MLP go through the igemm path.
 #include "common.h"
 
-// out[b*T + t][:] = tok[ids[b][t]][:] + pos[t][:]      (fp16 tables, fp32 add)
-__global__ void k_embed_tokens(const int64_t* __restrict__ ids, const half_t* __restrict__ tok,
-                               const half_t* __restrict__ pos, half_t* __restrict__ out, int rows, int T, int W, int vocab) {
-    const int P = W >> 3;
+// out[b*T + t][:] = tok[ids[b][t]][:] + pos[t][:]: fp32 tables, fp32 sum, fp32 out.  nn.Embedding is not an autocast op: the
+// reference's residual stream starts in fp32 and stays fp32 (fp16 branch outputs are promoted when added to it).
+__global__ void k_embed_tokens(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                               const float* __restrict__ pos, float* __restrict__ out, int rows, int T, int W, int vocab) {
+    const int P = W >> 2;
     const size_t n = (size_t)rows * P;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const size_t r = i / P;
         const int o = (int)(i - r * P);
         long id = ids[r];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-        const h8 a = *(const h8*)(tok + (size_t)id * W + (o << 3));
-        const h8 b = *(const h8*)(pos + (size_t)(r % T) * W + (o << 3));
-        h8 y;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)a[e] + (float)b[e]);
-        *(h8*)(out + r * W + (o << 3)) = y;
+        const f32x4 a = *(const f32x4*)(tok + (size_t)id * W + (o << 2));
+        const f32x4 b = *(const f32x4*)(pos + (size_t)(r % T) * W + (o << 2));
+        f32x4 y = {a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+        *(f32x4*)(out + r * W + (o << 2)) = y;
     }
 }
-int embed_tokens(const int64_t* ids, const half_t* tok, const half_t* pos, half_t* out, int rows, int T, int W, int vocab,
+int embed_tokens(const int64_t* ids, const float* tok, const float* pos, float* out, int rows, int T, int W, int vocab,
                  hipStream_t s) {
     if (rows <= 0 || T <= 0 || (W & 7) || vocab <= 0) return FGDM_ERR_ARG;
-    size_t g = ((size_t)rows * (W >> 3) + 255) / 256;
+    size_t g = ((size_t)rows * (W >> 2) + 255) / 256;
     hipLaunchKernelGGL(k_embed_tokens, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, ids, tok, pos, out, rows, T, W, vocab);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }

@@ -232,11 +232,20 @@ class Engine:
         # The conditioning is the same tensor OBJECT in every denoising step: its to_k / to_v projections are computed
         # once (fgdm_set_context) and reused while that object is unmodified (torch bumps _version on in-place writes;
         # holding the object keeps its storage from being recycled under the same address).
+        ctx_arg = None
         if self.cache_context and ctx.is_cuda and ctx.dtype == torch.float32 and ctx.is_contiguous():
-            if not (ctx is self._ctx_obj and ctx._version == self._ctx_ver):
-                self._check(self.lib.fgdm_set_context(self.h, _ptr(ctx), B, _stream()), 'fgdm_set_context')
-                self._ctx_obj, self._ctx_ver = ctx, ctx._version
-            ctx_arg = None
+            if ctx is self._ctx_obj and ctx._version == self._ctx_ver:
+                self._ctx_thrash = 0
+            else:
+                # callers that ALTERNATE two contexts (guess mode: the conditional and the unconditional call of every step,
+                # controlnet/cldm/ddim_hacked.py:190-191) would re-register (free + ~50 hipMallocs + a sync) on every call:
+                # after two misses in a row the context is simply passed along and projected from the workspace instead
+                self._ctx_thrash = getattr(self, '_ctx_thrash', 0) + 1
+                if self._ctx_thrash <= 1:
+                    self._check(self.lib.fgdm_set_context(self.h, _ptr(ctx), B, _stream()), 'fgdm_set_context')
+                    self._ctx_obj, self._ctx_ver = ctx, ctx._version
+                else:
+                    ctx_arg = ctx
         else:
             ctx_arg = ctx.to(self.device, torch.float32).contiguous()
         eps = torch.empty_like(x) if out is None else out

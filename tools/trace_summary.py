@@ -12,9 +12,9 @@ import numpy as np
 def family(name):
     if 'igemm' in name or 'splitk_reduce' in name:
         return 'igemm'
-    if 'attn_kernel' in name:
+    if 'attn' in name:
         return 'attention'
-    if 'gn_' in name or 'ln_kernel' in name:
+    if 'gn_' in name or 'ln_kernel' in name or 'row_stats' in name:
         return 'norm'
     return 'other'
 
