@@ -41,15 +41,14 @@ __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
 }
 
-// rstd (acc - mean u) + b with a FIXED rounding sequence (one fma, one multiply, one add; no contraction), the same in the
-// 2-stage kernel: which kernel evaluates a layer must not change a bit of its output
-__device__ __forceinline__ float ln_fix(float acc, float mean, float rstd, float u, float b) {
-    // inline asm: with -ffp-contract=fast the backend fuses a multiply into a following add whatever the source says
-    float t, w, r;
+// rstd (acc - mean u): one fma and one multiply as inline asm -- with -ffp-contract=fast the backend fuses a multiply into the
+// bias add that follows whatever the source says; the 2-stage kernel (igemm.hip) rounds in exactly this sequence, and WHICH
+// kernel evaluates a layer must not change a bit of its output
+__device__ __forceinline__ float ln_scale(float acc, float mean, float rstd, float u) {
+    float t, w;
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(-mean), "v"(u), "v"(acc));
     asm("v_mul_f32 %0, %1, %2" : "=v"(w) : "v"(rstd), "v"(t));
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(w), "v"(b));
-    return r;
+    return w;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -65,9 +64,8 @@ constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (m
 // v_mfma_f32_32x32x16_f16 (two k-substeps per 32x32 tile).  Same flops, same LDS bytes, same accumulator registers; the
 // chip holds a higher clock under the 16x16x32 shape (this kernel is power-limited: all-zero operands run 1.3x faster
 // than random ones), measured +3..9 % on the conv shapes (tools/bench_igemm.py cfg 4 vs 7).
-// LN: the consumer side of a folded LayerNorm (IgemmArgs::ln_stats) is its own instantiation: the (mean, rstd, u) fix-up in the
-// register stage does not fit next to the 160 accumulator registers of the 256x320 tile (208 bytes of scratch per lane when
-// it was a run-time branch there), so LN consumers use the 128x320 / 256x256 tiles and every other layer pays nothing
+// LN: the consumer side of a folded LayerNorm (IgemmArgs::ln_stats) is its own instantiation, so every other layer pays nothing
+// for it (as a run-time branch inside the register stage it cost the 256x320 tile 208 bytes of scratch per lane)
 template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN>
 __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, T = NW * 64;
@@ -323,6 +321,25 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     // MS = 16: acc[j][i][r]: channel = n0 + wn*TN + j*16 + 4*lh + r            ; pixel = m0 + wm*TM + i*16 + lrow
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // all waves are out of the K loop: the ring is free for staging
+    if constexpr (LN) {
+        // LayerNorm folded into this GEMM: acc <- rstd_m (acc - mean_m u_n), IN PLACE and before anything else (the bias, which
+        // carries beta W, is added by the ordinary epilogue below): one column quad of u and one row's (mean, rstd) live at a time,
+        // so the fix-up costs no registers next to the accumulators.  fma + mul as inline asm: see ln_scale.
+        const float* uw = u_l + wn * TN;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int g = 0; g < AR / 4; ++g) {
+                const f32x4 uq = *(const f32x4*)(uw + j * MS + (MS == 32 ? 8 * g : 0) + lq);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int trow = wm * TM + i * MS + lrow;            // row inside the tile
+                    const float mean = mr_l[2 * trow], rstd = mr_l[2 * trow + 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][i][g * 4 + e] = ln_scale(acc[j][i][g * 4 + e], mean, rstd, uq[e]);
+                }
+            }
+    }
     constexpr int OUT_TN = GEGLU ? TN / 2 : TN;          // output channels this wave produces
     constexpr int PITCH = OUT_TN * 2 + 8;                // wave-private staging tile: 32 pixels x OUT_TN fp16
     constexpr int CPR = OUT_TN / 8;                      // 16-byte chunks per pixel row
@@ -349,9 +366,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         const int row = m0 + wm * TM + ip * 32 + prow;    // ... and in the whole problem
         const int bsmp = (a.rowvec && row < a.M) ? row / rps : smp0;
         const float* rw = rv_l + (bsmp - smp0) * BN + wn * TN;
-        const int trow = wm * TM + ip * 32 + prow;           // row inside the tile
-        const float ln_mean = LN ? mr_l[2 * trow] : 0.f, ln_rstd = LN ? mr_l[2 * trow + 1] : 1.f;
-        const float* uw = u_l + wn * TN;
         // ---- registers -> (bias, emb, activation, scale) -> fp16 -> LDS [pixel][channel]
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -361,14 +375,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 const int wc = j * MS + (MS == 32 ? 8 * g : 0) + lq;      // packed channel inside the wave tile
                 const f32x4 bq = *(const f32x4*)(bw + wc);
                 float v[4];
-                if constexpr (LN) {
-                    const f32x4 uq = *(const f32x4*)(uw + wc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ln_fix(acc[j][i][g * 4 + e], ln_mean, ln_rstd, uq[e], bq[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e] + bq[e];
-                }
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e] + bq[e];
                 if (a.rowvec) {
                     if (rv_in_lds) {
                         const f32x4 rq = *(const f32x4*)(rw + wc);
@@ -389,14 +397,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 if constexpr (GEGLU) {      // packed rows: 64-row groups [32 value | 32 gate]
                     constexpr int GJ = MS == 32 ? 1 : 2;                 // gate tile = value tile + GJ
                     const f32x4 gq = *(const f32x4*)(bw + wc + 32);
-                    if constexpr (LN) {
-                        const f32x4 ug = *(const f32x4*)(uw + wc + 32);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= gelu_f(ln_fix(acc[j + GJ][i][g * 4 + e], ln_mean, ln_rstd, ug[e], gq[e]));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j + GJ][i][g * 4 + e] + gq[e]);
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j + GJ][i][g * 4 + e] + gq[e]);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= a.scale;
@@ -576,9 +578,11 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if (a.ln_stats) {       // LayerNorm consumers: the LN instantiations (128x320 in place of 256x320, see igemm2_kernel)
         if (a.mode != IG_LINEAR || a.splitk > 1) return FGDM_ERR_ARG;
         switch (cfg) {
-            case 0: case 2: return launch2ln<128, 320, 4, 2, 4, false>(a, s);
+            case 0: return launch2ln<256, 320, 4, 2, 4, false>(a, s);
+            case 2: return launch2ln<128, 320, 4, 2, 4, false>(a, s);
             case 1: return g ? launch2ln<256, 256, 4, 2, 4, true>(a, s) : launch2ln<256, 256, 4, 2, 4, false>(a, s);
-            case 3: case 5: return launch2ln<128, 320, 4, 2, 4, false, 32>(a, s);
+            case 3: return launch2ln<256, 320, 4, 2, 4, false, 32>(a, s);
+            case 5: return launch2ln<128, 320, 4, 2, 4, false, 32>(a, s);
             case 4: return g ? launch2ln<256, 256, 4, 2, 4, true, 32>(a, s) : launch2ln<256, 256, 4, 2, 4, false, 32>(a, s);
             default: return FGDM_ERR_ARG;
         }
