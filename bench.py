@@ -41,7 +41,7 @@ def log(msg):
     print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
 
-def build_model(rank, world, device, first_stage=True, n_controlnets=1):
+def build_model(rank, world, device, first_stage=True, n_controlnets=1, force_bcast=False):
     """ControlLDM mirror (reference API) over the HIP engine; frozen weights are generated on rank 0 only and
     shipped with ONE RCCL broadcast of a flat buffer (fp16 where the engine keeps fp16; fgdm_amd/dist.py)."""
     from fgdm_amd import dist as fd, models, synth
@@ -50,7 +50,7 @@ def build_model(rank, world, device, first_stage=True, n_controlnets=1):
                               first_stage_config=True if first_stage else None)
     shapes = model.engine.param_shapes()
     timing = {}
-    sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, device, timing)
+    sd, flat = fd.broadcast_weights(shapes, synth.make_tensor, rank, world, device, timing, force=force_bcast)
     missing, _ = model.load_state_dict(sd, strict=True)
     assert not missing
     n_params = sum(int(np.prod(s)) for s in shapes.values())
@@ -161,6 +161,14 @@ def main():
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))       # nothing has touched the GPU yet
+    # stdout carries exactly ONE line, the JSON: native libraries write there too (RCCL prints a version banner on the first
+    # collective), so file descriptor 1 is pointed at stderr for the whole run and the JSON goes to a saved copy of it
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + '\n').encode())
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -175,9 +183,14 @@ def main():
     if not a.dry_run:
         torch.cuda.set_device(local)
     import torch.distributed as dist
-    if world > 1:
+    # FGDM_BENCH_FORCE_DIST=1: take the collective code paths (process group, broadcast, barrier, all_reduce, all_gather) even
+    # with ONE rank -- the only way to run them over RCCL on a one-GPU box before the 8-GPU driver run does
+    use_dist = world > 1 or os.environ.get('FGDM_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(a.backend, rank=rank, world_size=world)
+        os.environ.setdefault('MASTER_PORT', '29513')
+        kw = {'device_id': torch.device('cuda', local)} if a.backend == 'nccl' else {}
+        dist.init_process_group(a.backend, rank=rank, world_size=world, **kw)
 
     if os.environ.get('FGDM_BENCH_FAIL_RANK') == str(rank):     # tests: a dying rank must fail the whole launch
         sys.exit(3)
@@ -188,7 +201,8 @@ def main():
         engine = None
         sampler = samplers.DDIMSampler(model)
     else:
-        model, n_params, wt = build_model(rank, world, dev, first_stage=not a.no_first_stage, n_controlnets=a.controlnets)
+        model, n_params, wt = build_model(rank, world, dev, first_stage=not a.no_first_stage, n_controlnets=a.controlnets,
+                                          force_bcast=use_dist)
         engine = model.engine
         sampler = samplers.ControlDDIMSampler(model)       # drop-in for controlnet/cldm/ddim_hacked.py:DDIMSampler
     load_s = wt['load_s']
@@ -219,7 +233,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         if not a.dry_run:
             torch.cuda.synchronize()
@@ -243,7 +257,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = engine.profile_end() if engine is not None else None
     per_rank = [npg * a.steps / dt_own]
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -253,13 +267,13 @@ def main():
     assert torch.isfinite(out).all(), 'non-finite latents'
     if a.dry_run:
         if rank == 0:
-            print(json.dumps({'metric': '512x512 images/sec @ 50 DDIM steps, seg-ControlNet+CFG', 'dry_run': True, 'value': None,
+            emit({'metric': '512x512 images/sec @ 50 DDIM steps, seg-ControlNet+CFG', 'dry_run': True, 'value': None,
                               'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'backend': a.backend,
                               'ms_per_step': dt / a.steps * 1e3, 'scaling': 'weak', 'per_rank_images_per_s': per_rank,
                               'weights': {'params': n_params, 'bcast_s': wt.get('bcast_s'), 'bcast_bytes': wt.get('bcast_bytes')},
                               'config': {'workload': 'DRY RUN: analytic stand-in model on CPU, launcher/shard/broadcast rehearsal only',
-                                         'prompts_per_gpu': npg}}), flush=True)
-        if world > 1:
+                                         'prompts_per_gpu': npg}})
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -337,8 +351,8 @@ def main():
         log(f'{value:.3f} images/s; igemm {achieved:.0f} TFLOP/s')
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        emit(res)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -30,7 +30,7 @@ def _ships_as_fp16(key, shape):
     return len(shape) >= 2 and not key.endswith('to_q.weight')
 
 
-def broadcast_weights(shapes, make_tensor, rank, world, device, timing=None):
+def broadcast_weights(shapes, make_tensor, rank, world, device, timing=None, force=False):
     """Rank 0 materialises every parameter (make_tensor(key, shape) -> float32 ndarray) into ONE flat byte buffer -- fp16
     where the engine keeps fp16 (2.5 GB for SD-v1.5 + one ControlNet instead of 4.9 GB of fp32), fp32 otherwise -- a single
     broadcast ships it (RCCL over xGMI on GPUs, gloo in the CPU tests) and every rank returns {key: view} plus the
@@ -49,7 +49,7 @@ def broadcast_weights(shapes, make_tensor, rank, world, device, timing=None):
             o, nbytes, dt = layout[k]
             src = torch.from_numpy(np.ascontiguousarray(make_tensor(k, s), dtype=np.float32).ravel()).to(dt)
             flat[o:o + nbytes].view(dt).copy_(src)
-    if world > 1:
+    if world > 1 or force:      # force: issue the collective even for one rank (rehearsal of the RCCL call)
         if flat.is_cuda:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
