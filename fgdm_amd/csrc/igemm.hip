@@ -329,13 +329,14 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 static int g_force_cfg = 0;
 void igemm_set_force_cfg(int cfg) { g_force_cfg = cfg; }
 
-// tile configuration for `a` (0 = the 2-stage kernel picks one of its own tiles; 4..9 = pipelined kernel cfg 0..5)
+// tile configuration for `a` (0 = the 2-stage kernel picks one of its own tiles; 4..10 = pipelined kernel cfg 0..6)
 static int pick_force(const IgemmArgs& a) {
     int force = a.force_cfg ? a.force_cfg : g_force_cfg;
     if (a.act == ACT_QGELU) {                   // the pipelined kernel's epilogue does not carry quick-GELU (text encoder only)
         if (force >= 4) force = 0;
         if (force == 0) return 0;
     }
+    static const bool other_widths = !(getenv("FGDM_IGEMM_OTHER_WIDTHS") && atoi(getenv("FGDM_IGEMM_OTHER_WIDTHS")) == 0);   // A/B knob
     if (force == 0) {
         const bool geglu = a.act == ACT_GEGLU;
         if (!geglu && a.N % 320 == 0) {
@@ -345,6 +346,12 @@ static int pick_force(const IgemmArgs& a) {
             else if (b128 >= 96) force = 6;
         } else if (geglu && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= 128) {
             force = 5;
+        } else if (!geglu && !a.ln_stats && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && other_widths) {
+            // widths that are not multiples of 320 (the autoencoder's 128 / 256 / 512, the hint block's 256): 256-row tiles
+            // over 256 or 128 columns once the grid fills the chip (at 210 TFLOP/s the 2-stage kernel was the decoder's bound)
+            const long rows = (a.M + 255) / 256;
+            if (a.N % 256 == 0 && rows * (a.N / 256) >= 192) force = 5;
+            else if (a.N == 128 && rows >= 192) force = 10;
         }
     }
     return force;

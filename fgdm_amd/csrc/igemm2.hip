@@ -444,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                     const char* sp = cst + pr * PITCH + ck * 16;
                     const h4 lo = *(const h4*)sp, hi = *(const h4*)(sp + 8);
                     v[it] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (a.resid) rr[it] = *(const h8*)(a.resid + (size_t)grow * a.ld_res + gcol);
+                    if (a.resid && !(a.debug & 16)) rr[it] = *(const h8*)(a.resid + (size_t)grow * a.ld_res + gcol);
                 }
             }
             bool want_stats = false;
@@ -454,11 +454,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 #pragma unroll
             for (int it = 0; it < WB_IT; ++it) {
                 if (ok[it]) {
-                    if (a.resid) {
+                    if (a.resid && !(a.debug & 16)) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[it][e] = (half_t)((float)v[it][e] + (float)rr[it][e]);
                     }
-                    *(h8*)((half_t*)outp + goff[it]) = v[it];
+                    if (!(a.debug & 32) || v[it][0] == (half_t)12345.f) *(h8*)((half_t*)outp + goff[it]) = v[it];
                 }
                 if (want_stats) {
                     // LayerNorm partial sums of the rows just written, from the STORED fp16 values: this lane's 8 channels
@@ -570,7 +570,7 @@ int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
 //      3..5 = the same tiles on the 32x32x16 MFMA (kept for A/B measurements: tools/bench_igemm.py cfg 7..9)
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if ((a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return FGDM_ERR_ARG;
-    const int bn = (cfg == 1 || cfg == 4) ? 256 : 320;
+    const int bn = (cfg == 1 || cfg == 4) ? 256 : cfg == 6 ? 128 : 320;
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
     const bool g = a.act == ACT_GEGLU;
     if (g && bn != 256) return FGDM_ERR_ARG;
@@ -598,6 +598,7 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
         case 3: return launch2m<256, 320, 4, 2, 4, false, 32>(a, s);
         case 4: return g ? launch2m<256, 256, 4, 2, 4, true, 32>(a, s) : launch2m<256, 256, 4, 2, 4, false, 32>(a, s);
         case 5: return launch2m<128, 320, 4, 2, 4, false, 32>(a, s);
+        case 6: return launch2m<256, 128, 4, 2, 4, false>(a, s);        // N = 128 (the autoencoder's full-resolution level)
         default: return FGDM_ERR_ARG;
     }
 }

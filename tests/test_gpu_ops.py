@@ -250,6 +250,15 @@ BIG_CASES = [
 ]
 # cfg 4..6 run the 16x16x32 MFMA; cfg 7..9 are the same tiles on the 32x32x16 MFMA (kept for A/B measurements)
 BIG_CASES = BIG_CASES + [(c[0] + 3,) + c[1:-1] + (c[-1].replace('cfg%d' % c[0], 'cfg%d(mfma32)' % (c[0] + 3)),) for c in BIG_CASES]
+# widths that are not multiples of 320 (AutoencoderKL 128 / 256 / 512, hint block 256): 256x256 and 256x128 tiles
+BIG_CASES += [
+    (5, 3, 16, 16, 128, 0, 512, 3, 1, 0, 1, 'cfg5 N=512 conv silu + rowvec + resid, M tail'),
+    (5, 2, 8, 8, 512, 0, 256, 3, 1, 1, 0, 'cfg5 N=256 upsample'),
+    (5, 2, 16, 16, 512, 0, 512, 1, 1, 0, 0, 'cfg5 N=512 conv1x1'),
+    (10, 3, 16, 16, 128, 0, 128, 3, 1, 0, 0, 'cfg10 N=128 conv + rowvec + resid, M tail'),
+    (10, 2, 8, 8, 256, 0, 128, 3, 1, 1, 1, 'cfg10 N=128 upsample silu'),
+    (10, 1, 8, 8, 256, 0, 128, 1, 1, 0, 0, 'cfg10 N=128 conv1x1'),
+]
 
 
 @pytest.mark.parametrize('case', BIG_CASES, ids=[c[-1] for c in BIG_CASES])
