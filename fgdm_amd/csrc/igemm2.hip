@@ -11,6 +11,7 @@
 //     row-contiguous stores with a 16-byte residual read (the old 2-byte stores cost ~135 us per 84 MB tensor).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
@@ -66,7 +67,7 @@ constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (m
 // than random ones), measured +3..9 % on the conv shapes (tools/bench_igemm.py cfg 4 vs 7).
 // LN: the consumer side of a folded LayerNorm (IgemmArgs::ln_stats) is its own instantiation, so every other layer pays nothing
 // for it (as a run-time branch inside the register stage it cost the 256x320 tile 208 bytes of scratch per lane)
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH>
 __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, T = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -357,6 +358,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 
     constexpr int PT = 32 / MS;                          // MFMA pixel tiles per 32-pixel staging pass
     constexpr int NG = AR / 4;                           // 4-channel register quads per accumulator tile
+    // The passes below are straight-line code 40 register quads long.  PATH 0 is the general form: output kind, activation and
+    // the source of the emb row are block-uniform RUN-TIME branches inside every quad (1450 branches and 78 KB of code in the
+    // 256x320 kernel, the hot path threading through all of it).  PATH 1 / 2 are the same code with the common answers compiled
+    // in -- fp16 row-major output, no activation (or GEGLU), no emb row (1) / emb rows staged in LDS (2) -- chosen by the host
+    // (epilogue_path); they differ from PATH 0 in nothing but the branches.
 #pragma unroll
     for (int ip = 0; ip < TM / 32; ++ip) {
 #pragma unroll
@@ -377,8 +383,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[j][i][g * 4 + e] + bq[e];
-                if (a.rowvec) {
-                    if (rv_in_lds) {
+                if (PATH == 2 || (PATH == 0 && a.rowvec)) {
+                    if (PATH == 2 || rv_in_lds) {
                         const f32x4 rq = *(const f32x4*)(rw + wc);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rq[e];
@@ -387,10 +393,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                         for (int e = 0; e < 4; ++e) v[e] += a.rowvec[(size_t)bsmp * a.rv_stride + n0 + wn * TN + wc + e];
                     }
                 }
-                if (a.act == ACT_SILU) {
+                if (PATH == 0 && a.act == ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                } else if (a.act == ACT_RELU) {
+                } else if (PATH == 0 && a.act == ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 for (int e = 0; e < 4; ++e) v[e] *= a.scale;
                 // output channel inside the wave tile (GEGLU: value channels only, 32 per 64-row group)
                 const int oc = !GEGLU ? wc : (MS == 32 ? (j >> 1) * 32 + 8 * g + lq : (j >> 2) * 32 + (j & 1) * 16 + lq);
-                if (okind == OUT_F16) {
+                if (PATH != 0 || okind == OUT_F16) {
                     h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     *(h4*)(cst + prow * PITCH + oc * 2) = pk;
                 } else if (row < a.M && ocol0 + oc < nvalid) {
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
             }
         }
       }
-        if (okind == OUT_F16) {
+        if (PATH != 0 || okind == OUT_F16) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private tile: no barrier needed
             // ---- LDS -> (+ residual) -> 16-byte row-contiguous global stores; all loads first, then all stores
             h8 v[WB_IT], rr[WB_IT];
@@ -454,10 +460,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 #pragma unroll
             for (int it = 0; it < WB_IT; ++it) {
                 if (ok[it]) {
-                    if (a.resid && !(a.debug & 16)) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[it][e] = (half_t)((float)v[it][e] + (float)rr[it][e]);
-                    }
+                    // fp16 + fp16 rounded once: the packed fp16 add IS the fp32 add followed by a rounding (24 >= 2 * 11 + 2
+                    // significand bits: the double rounding is innocuous), at 4 instructions per 8 channels instead of 32
+                    if (a.resid && !(a.debug & 16)) v[it] = v[it] + rr[it];
                     if (!(a.debug & 32) || v[it][0] == (half_t)12345.f) *(h8*)((half_t*)outp + goff[it]) = v[it];
                 }
                 if (want_stats) {
@@ -494,14 +499,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     }   // !SPLIT
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false, int MS = 16, bool LN = false>
-int launch2(const IgemmArgs& a, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH>
+int launch2p(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4 + (2 * BM + BN) * 4;      // + staged bias, emb rows, LayerNorm (mean, rstd), u
     static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN>;
+    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -510,15 +515,37 @@ int launch2(const IgemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(ntm * ntn * (SPLIT ? a.splitk : 1)), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
+// Which epilogue PATH serves `a` (see igemm2_kernel): 1 / 2 need the fp16 row-major output without an activation (GEGLU is
+// its own instantiation); 2 also needs every tile's emb rows to fit the LDS staging area (a BM-row tile touches at most
+// (BM - 1) / rows_per_sample + 2 samples)
+template <int BM, bool GEGLU>
+int epilogue_path(const IgemmArgs& a) {
+    if (a.out_kind != OUT_F16 || (a.out2 && a.out_kind2 != OUT_F16) || !(a.act == ACT_NONE || GEGLU)) return 0;
+    if (!a.rowvec) return 1;
+    return (BM - 1) / a.rows_per_sample + 2 <= RV_MAX ? 2 : 0;
+}
+// FAST: also build the specialised epilogues (the hot tile configurations); otherwise PATH 0 only
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false, int MS = 16, bool LN = false, bool FAST = false>
+int launch2(const IgemmArgs& a, hipStream_t s) {
+    static const bool fast_on = !(getenv("FGDM_IGEMM_EPI_PATHS") && atoi(getenv("FGDM_IGEMM_EPI_PATHS")) == 0);   // A/B knob
+    if constexpr (FAST && !SPLIT) {
+        switch (fast_on ? epilogue_path<BM, GEGLU>(a) : 0) {
+            case 1: return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 1>(a, s);
+            case 2: if constexpr (!GEGLU && !LN) return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 2>(a, s);
+            default: break;
+        }
+    }
+    return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 0>(a, s);
+}
 template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU, int MS = 16>
 int launch2m(const IgemmArgs& a, hipStream_t s) {
-    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS>(a, s)
-                               : launch2<BM, BN, WM, WN, STAGES, true, GEGLU, false, MS>(a, s);
+    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS, false, MS == 16>(a, s)
+                               : launch2<BM, BN, WM, WN, STAGES, true, GEGLU, false, MS, false, MS == 16>(a, s);
 }
 // consumer of a folded LayerNorm: always a LINEAR GEMM
 template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU, int MS = 16>
 int launch2ln(const IgemmArgs& a, hipStream_t s) {
-    return launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS, true>(a, s);
+    return launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS, true, MS == 16>(a, s);
 }
 
 // out[m][n] = ((sum_s ws[s][m][n]) + bias + emb -> act) * scale + resid, fixed summation order
