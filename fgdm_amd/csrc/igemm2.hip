@@ -346,12 +346,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     constexpr int CPR = OUT_TN / 8;                      // 16-byte chunks per pixel row
     constexpr int WB_IT = (32 * CPR + 63) / 64;          // writeback iterations per lane
     static_assert(!GEGLU || NI % 2 == 0, "GEGLU needs value/gate tile pairs");
-    char* cst = smem + wave * (32 * PITCH);
+    // PATH 1 of the LayerNorm consumers also serves a TRANSPOSED second destination (V^T of the stacked q|k|v projection):
+    // that tile is staged [channel][pixel] and leaves as 16-byte runs along the token axis (the general path's 2-byte stores
+    // were the slowest part of that GEMM); the host guarantees rows_per_sample % 32 == 0, so a 32-pixel pass has ONE sample
+    constexpr bool TR = PATH == 1 && LN && !GEGLU;
+    constexpr int TPITCH = 32 * 2 + 16;                  // [channel][32 pixels] fp16
+    constexpr int CST_BYTES = TR && OUT_TN * TPITCH > 32 * PITCH ? OUT_TN * TPITCH : 32 * PITCH;
+    static_assert(NW * CST_BYTES <= RING_BYTES, "epilogue staging must fit in the ring");
+    char* cst = smem + wave * CST_BYTES;
     // destination of this tile (block-uniform): the second one for packed columns >= split_n
     const bool second = a.out2 && n0 >= a.split_n;
     void* const outp = second ? a.out2 : a.out;
     const int okind = second ? a.out_kind2 : a.out_kind, ldo = second ? a.ld_out2 : a.ld_out;
     const int ncol0 = second ? a.split_n : 0, nend = a.out2 ? (second ? a.N : a.split_n) : a.N;
+    const bool tr = TR && okind == OUT_F16_T;
     const int ocol0 = GEGLU ? ((n0 + wn * TN) >> 1) : (n0 + wn * TN - ncol0);   // first output column of this wave
     const int nvalid = GEGLU ? a.N / 2 : nend - ncol0;                          // valid output columns of the destination
     const float* bw = bias_l + wn * TN;                                  // this wave's slice of the staged bias
@@ -410,7 +418,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 for (int e = 0; e < 4; ++e) v[e] *= a.scale;
                 // output channel inside the wave tile (GEGLU: value channels only, 32 per 64-row group)
                 const int oc = !GEGLU ? wc : (MS == 32 ? (j >> 1) * 32 + 8 * g + lq : (j >> 2) * 32 + (j & 1) * 16 + lq);
-                if (PATH != 0 || okind == OUT_F16) {
+                if (TR && tr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *(half_t*)(cst + (oc + e) * TPITCH + prow * 2) = (half_t)v[e];
+                } else if (PATH != 0 || okind == OUT_F16) {
                     h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     *(h4*)(cst + prow * PITCH + oc * 2) = pk;
                 } else if (row < a.M && ocol0 + oc < nvalid) {
@@ -432,7 +443,23 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
             }
         }
       }
-        if (PATH != 0 || okind == OUT_F16) {
+        if (TR && tr) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int row0 = m0 + wm * TM + ip * 32;              // 32 tokens of one sample: 64-byte runs per channel
+            const int b = row0 / rps, t0 = row0 - b * rps;
+            constexpr int TT = OUT_TN * 4;                        // (channel, 8-token chunk) tasks
+            if (row0 < a.M) {
+#pragma unroll
+                for (int it = 0; it < (TT + 63) / 64; ++it) {
+                    const int task = lane + it * 64, c = task >> 2, q = task & 3;
+                    if (task < TT && ocol0 + c < nvalid) {
+                        const h8 val = *(const h8*)(cst + c * TPITCH + q * 16);
+                        *(h8*)((half_t*)outp + ((size_t)b * nvalid + ocol0 + c) * ldo + t0 + q * 8) = val;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
+        } else if (PATH != 0 || okind == OUT_F16) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private tile: no barrier needed
             // ---- LDS -> (+ residual) -> 16-byte row-contiguous global stores; all loads first, then all stores
             h8 v[WB_IT], rr[WB_IT];
@@ -450,7 +477,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                     const char* sp = cst + pr * PITCH + ck * 16;
                     const h4 lo = *(const h4*)sp, hi = *(const h4*)(sp + 8);
                     v[it] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (a.resid && !(a.debug & 16)) rr[it] = *(const h8*)(a.resid + (size_t)grow * a.ld_res + gcol);
+                    if (a.resid) rr[it] = *(const h8*)(a.resid + (size_t)grow * a.ld_res + gcol);
                 }
             }
             bool want_stats = false;
@@ -462,8 +489,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                 if (ok[it]) {
                     // fp16 + fp16 rounded once: the packed fp16 add IS the fp32 add followed by a rounding (24 >= 2 * 11 + 2
                     // significand bits: the double rounding is innocuous), at 4 instructions per 8 channels instead of 32
-                    if (a.resid && !(a.debug & 16)) v[it] = v[it] + rr[it];
-                    if (!(a.debug & 32) || v[it][0] == (half_t)12345.f) *(h8*)((half_t*)outp + goff[it]) = v[it];
+                    if (a.resid) v[it] = v[it] + rr[it];
+                    *(h8*)((half_t*)outp + goff[it]) = v[it];
                 }
                 if (want_stats) {
                     // LayerNorm partial sums of the rows just written, from the STORED fp16 values: this lane's 8 channels
@@ -503,7 +530,6 @@ template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, boo
 int launch2p(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4 + (2 * BM + BN) * 4;      // + staged bias, emb rows, LayerNorm (mean, rstd), u
-    static_assert(WM * WN * 32 * ((BN / WN) * 2 + 8) <= ring, "epilogue staging must fit in the ring");
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH>;
@@ -518,9 +544,14 @@ int launch2p(const IgemmArgs& a, hipStream_t s) {
 // Which epilogue PATH serves `a` (see igemm2_kernel): 1 / 2 need the fp16 row-major output without an activation (GEGLU is
 // its own instantiation); 2 also needs every tile's emb rows to fit the LDS staging area (a BM-row tile touches at most
 // (BM - 1) / rows_per_sample + 2 samples)
-template <int BM, bool GEGLU>
+template <int BM, bool GEGLU, bool LN>
 int epilogue_path(const IgemmArgs& a) {
-    if (a.out_kind != OUT_F16 || (a.out2 && a.out_kind2 != OUT_F16) || !(a.act == ACT_NONE || GEGLU)) return 0;
+    if (a.out_kind != OUT_F16 || !(a.act == ACT_NONE || GEGLU)) return 0;
+    if (a.out2 && a.out_kind2 != OUT_F16) {     // transposed second destination: staged by PATH 1 of the LayerNorm consumers
+        const bool staged = LN && a.out_kind2 == OUT_F16_T && a.rows_per_sample % 32 == 0 && a.M % 32 == 0 && a.ld_out2 % 8 == 0 &&
+                            ((size_t)a.out2 & 15) == 0;
+        if (!staged || a.rowvec) return 0;
+    }
     if (!a.rowvec) return 1;
     return (BM - 1) / a.rows_per_sample + 2 <= RV_MAX ? 2 : 0;
 }
@@ -529,7 +560,7 @@ template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, boo
 int launch2(const IgemmArgs& a, hipStream_t s) {
     static const bool fast_on = !(getenv("FGDM_IGEMM_EPI_PATHS") && atoi(getenv("FGDM_IGEMM_EPI_PATHS")) == 0);   // A/B knob
     if constexpr (FAST && !SPLIT) {
-        switch (fast_on ? epilogue_path<BM, GEGLU>(a) : 0) {
+        switch (fast_on ? epilogue_path<BM, GEGLU, LN>(a) : 0) {
             case 1: return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 1>(a, s);
             case 2: if constexpr (!GEGLU && !LN) return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 2>(a, s);
             default: break;

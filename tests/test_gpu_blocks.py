@@ -110,6 +110,22 @@ def test_spatial_transformer(eng, prefix, xkey):
            lambda: onn.spatial_transformer(p, tag, precision.st(x), precision.st(ctx), 8))
 
 
+@pytest.mark.parametrize('reps', [8, 32], ids=['128x320 tiles', '256x320 tiles'])
+def test_spatial_transformer_pipelined_tiles(eng, reps):
+    """The same block with the batch replicated until the 64x64-level tile configurations are chosen (M = 4096: 128x320,
+    M = 16384: 256x320): the stacked q|k|v GEMM with its transposed V^T destination, LayerNorm statistics from the
+    producers' epilogues, the straight-line epilogue paths.  Samples are independent, so every replica must repeat
+    the first pair bit for bit and that pair must match the golden."""
+    prefix, tag = U + 'input_blocks.1.1.', 'st320.'
+    x, ctx = gi.get('ops/st320_x'), gi.get('ops/ctx')
+    got = eng.run_block(prefix, x.repeat(reps, 1, 1, 1), ctx=ctx.repeat(reps, 1, 1)).cpu()
+    got = got.view(reps, -1)
+    assert torch.equal(got, got[:1].expand_as(got))
+    p = _params(prefix, tag, eng)
+    _check(f'SpatialTransformer st320 x{reps}', got[0], 'st320_y',
+           lambda: onn.spatial_transformer(p, tag, precision.st(x), precision.st(ctx), 8))
+
+
 def test_adapter(eng):
     pre = U + 'adapter.'
     x = gi.get('ops/adapter_x')

@@ -15,8 +15,7 @@ SHAPES = [
     ('L0 lin 1280->320 +res', 32, 64, 64, 1280, 0, 320, 1, 1, 0, 0, 1),
     ('L0 geglu 320->2560', 32, 64, 64, 320, 0, 2560, 1, 1, 0, 3, 0),
 ]
-BITS = [(0, 'full'), (16, 'no resid read'), (32, 'no stores'), (48, 'no resid, no stores'), (4, 'no epilogue'), (1, 'no K-loop loads'),
-        (1 + 48, 'no loads/resid/stores')]
+BITS = [(0, 'full'), (4, 'no epilogue'), (1, 'no K-loop loads'), (2, 'no MFMAs')]
 
 
 def main():
