@@ -10,6 +10,23 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// exact-erf GELU (ldm/modules/attention.py:43-44: F.gelu) as x Phi(x) with the lower Gaussian tail t = Phi(-|x|) written as
+// exp2 of a degree-5 polynomial in z = min(|x|, 6) (minimax fit of z |t^ - t|: |gelu^ - gelu| <= 8.2e-7 in fp32 over all x, far
+// below the fp16 resolution of the output), and x Phi(x) = x / 2 + |x| (1/2 - t): no reciprocal, no compare, 12 issue slots
+// per value where the Abramowitz-Stegun erfc form took 21 -- the GEGLU epilogue evaluates this 64 times per lane and tile.
+// One definition for both GEMM kernels: which of them runs a layer must not change its output.
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fminf(fabsf(x), 6.0f);
+    float p = -4.7132482596e-04f;
+    p = __builtin_fmaf(p, z, 7.0652551839e-03f);
+    p = __builtin_fmaf(p, z, -5.1762067461e-02f);
+    p = __builtin_fmaf(p, z, -4.6008771426e-01f);
+    p = __builtin_fmaf(p, z, -1.1507295505e+00f);
+    p = __builtin_fmaf(p, z, -4.8959157159e-05f - 1.0f);       // log2 t
+    const float t = __builtin_amdgcn_exp2f(p);
+    return __builtin_fmaf(fabsf(x), 0.5f - t, 0.5f * x);
+}
+
 #define FGDM_OK 0
 #define FGDM_ERR_ARG -1
 #define FGDM_ERR_HIP -2

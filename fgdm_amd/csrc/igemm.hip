@@ -24,14 +24,6 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact-erf GELU via Abramowitz-Stegun 7.1.26 erfc (|abs err| <= 1.5e-7), no 1 - erf cancellation (see igemm2.hip)
-__device__ __forceinline__ float gelu_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float pe = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
-}
 
 // rstd (acc - mean u): one fma and one multiply that must NOT be contracted with the bias add that follows -- the pipelined
 // kernel (igemm2.hip ln_fix) rounds in exactly this sequence, and which kernel runs a layer must not change a bit

@@ -32,16 +32,6 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_addr) {
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const void*)p; }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact-erf GELU (ldm/modules/attention.py:43-44) with erfc evaluated by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7,
-// far below fp16 output resolution); written without the 1 - erf cancellation for negative x.  13 VALU ops vs ~32.
-__device__ __forceinline__ float gelu_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float pe = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);     // erfc(|x| / sqrt 2)
-    return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
-}
-
 // rstd (acc - mean u): one fma and one multiply as inline asm -- with -ffp-contract=fast the backend fuses a multiply into the
 // bias add that follows whatever the source says; the 2-stage kernel (igemm.hip) rounds in exactly this sequence, and WHICH
 // kernel evaluates a layer must not change a bit of its output
