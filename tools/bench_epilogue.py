@@ -16,6 +16,8 @@ SHAPES = [
     ('L0 geglu 320->2560', 32, 64, 64, 320, 0, 2560, 1, 1, 0, 3, 0),
 ]
 BITS = [(0, 'full'), (4, 'no epilogue'), (1, 'no K-loop loads'), (2, 'no MFMAs')]
+if os.environ.get('CFG'):
+    BITS = [(0, 'auto')] + [(int(c) / 256.0, 'cfg %s' % c) for c in os.environ['CFG'].split(',')]
 
 
 def main():
@@ -28,7 +30,7 @@ def main():
         row = name.ljust(24)
         for bits, _ in BITS:
             ms = C.c_float()
-            rc = lib.fgdm_bench_igemm(B, H, W, C0, C1, Co, ks, st, up, act, res, bits << 8, a.iters, C.byref(ms))
+            rc = lib.fgdm_bench_igemm(B, H, W, C0, C1, Co, ks, st, up, act, res, int(bits * 256), a.iters, C.byref(ms))
             row += (f'{ms.value * 1e3:7.0f} us' if rc == 0 else '-').rjust(22)
         print(row, flush=True)
 
