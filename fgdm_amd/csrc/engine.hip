@@ -2250,7 +2250,7 @@ int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, i
     a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.mode = mode;
     a.M = (int)M; a.N = Cout; a.K = K; a.act = act; a.out_kind = OUT_F16; a.out = out; a.ld_out = nout;
     a.rows_per_sample = Ho * Wo; a.scale = 1.f; a.force_cfg = cfg & 0xff; a.debug = (cfg >> 8) & 0xff;
-    if (cfg == 0) {
+    if ((cfg & 0xff) == 0) {
         a.splitk = igemm_splitk_factor(a);
         if (a.splitk > 1) {
             if (hipMalloc(&a.ws, (size_t)a.splitk * a.M * a.N * sizeof(float)) != hipSuccess) return FGDM_ERR_NOMEM;
