@@ -27,6 +27,12 @@ __device__ __forceinline__ float gelu_f(float x) {
     return __builtin_fmaf(fabsf(x), 0.5f - t, 0.5f * x);
 }
 
+// x sigmoid(k x) (SiLU: k = 1; CLIP's quick-GELU: k = 1.702) with exp2 and the hardware reciprocal (1 ulp): the IEEE division
+// `x / (1 + exp(-x))` expands to ten instructions per value and made the GroupNorm+SiLU pass VALU-bound.  Shared by every kernel.
+__device__ __forceinline__ float silu_f(float x, float k = 1.0f) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * k * x));
+}
+
 #define FGDM_OK 0
 #define FGDM_ERR_ARG -1
 #define FGDM_ERR_HIP -2

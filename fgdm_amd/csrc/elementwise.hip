@@ -49,7 +49,7 @@ int nhwc_f16_to_nchw_f32(const half_t* x, float* y, int B, int C, int HW, hipStr
 }
 // y = fp16(SiLU(x)): the `emb_layers` input of a ResBlock (openaimodel.py:238-244) when `emb` is handed in from outside
 __global__ void k_silu_f32_to_f16(const float* __restrict__ x, half_t* __restrict__ y, size_t n) {
-    EW_LOOP(i, n) { const float v = x[i]; y[i] = (half_t)(v / (1.0f + __expf(-v))); }
+    EW_LOOP(i, n) { const float v = x[i]; y[i] = (half_t)silu_f(v); }
 }
 int silu_f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_silu_f32_to_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, y, n);

@@ -23,7 +23,6 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const GLB_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // rstd (acc - mean u): one fma and one multiply that must NOT be contracted with the bias add that follows -- the pipelined
 // kernel (igemm2.hip ln_fix) rounds in exactly this sequence, and which kernel runs a layer must not change a bit
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
                     float x = acc[i][j][g * 4 + e] + bias + rvv[g * 4 + e];
                     if (a.act == ACT_SILU) x = silu_f(x);
                     else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
-                    else if (a.act == ACT_QGELU) x = x / (1.0f + __expf(-1.702f * x));
+                    else if (a.act == ACT_QGELU) x = silu_f(x, 1.702f);
                     else if (geglu) {
                         if constexpr (NI >= 2) x = x * gelu_f(acc[i][j | 1][g * 4 + e] + gbias);
                     }

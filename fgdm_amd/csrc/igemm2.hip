@@ -31,7 +31,6 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_addr) {
                  : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const void*)p; }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // rstd (acc - mean u): one fma and one multiply as inline asm -- with -ffp-contract=fast the backend fuses a multiply into the
 // bias add that follows whatever the source says; the 2-stage kernel (igemm.hip) rounds in exactly this sequence, and WHICH
 // kernel evaluates a layer must not change a bit of its output
@@ -597,7 +596,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a) {
             if (a.rowvec) x += a.rowvec[(size_t)(row / a.rows_per_sample) * a.rv_stride + col + e];
             if (a.act == ACT_SILU) x = silu_f(x);
             else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
-            else if (a.act == ACT_QGELU) x = x / (1.0f + __expf(-1.702f * x));
+            else if (a.act == ACT_QGELU) x = silu_f(x, 1.702f);
             const half_t y = (half_t)(x * a.scale);                     // same two roundings as the fused epilogue
             o[e] = a.resid ? (half_t)((float)y + (float)r[e]) : y;
         }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu,
                                                         half_t* __restrict__ out) {
-    extern __shared__ float sc[];   // scale[C], shift[C], then stats[32][2]
+    extern __shared__ __attribute__((aligned(16))) float sc[];   // scale[C], shift[C], then stats[32][2]
     const int C = C0 + C1, P = C >> 3, cpg = C >> 5;
     const int b = blockIdx.y;
     float* scale = sc;
@@ -112,28 +112,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
         shift[c] = beta[c] - mean * w;
     }
     __syncthreads();
-    const size_t total = (size_t)HW * P;
+    const unsigned total = (unsigned)HW * (unsigned)P;     // < 2^31 (groupnorm_launch checks): 32-bit index arithmetic -- the
+    // 64-bit `i / P` of the first version expanded to ~60 instructions per octet
     // four independent 16-byte loads in flight per thread
-    for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < total; i0 += (size_t)gridDim.x * 1024) {
+    for (unsigned i0 = blockIdx.x * 1024u + threadIdx.x; i0 < total; i0 += gridDim.x * 1024u) {
         h8 v[4];
-        size_t pix[4];
+        unsigned pix[4];
         int oct[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const size_t i = i0 + (size_t)u * 256;
-            pix[u] = i / P;
-            oct[u] = (int)(i - pix[u] * P);
+            const unsigned i = i0 + (unsigned)u * 256u;
+            pix[u] = i / (unsigned)P;
+            oct[u] = (int)(i - pix[u] * (unsigned)P);
             if (i < total) v[u] = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + pix[u], oct[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + (size_t)u * 256 >= total) break;
+            if (i0 + (unsigned)u * 256u >= total) break;
             h8 r;
+            const f32x4 sc0 = *(const f32x4*)(scale + (oct[u] << 3)), sc1 = *(const f32x4*)(scale + (oct[u] << 3) + 4);
+            const f32x4 sh0 = *(const f32x4*)(shift + (oct[u] << 3)), sh1 = *(const f32x4*)(shift + (oct[u] << 3) + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int c = (oct[u] << 3) + e;
-                float f = (float)v[u][e] * scale[c] + shift[c];
-                if (silu) f = f / (1.0f + __expf(-f));
+                float f = (float)v[u][e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                if (silu) f = silu_f(f);
                 r[e] = (half_t)f;
             }
             *(h8*)(out + ((size_t)b * HW + pix[u]) * C + (oct[u] << 3)) = r;
@@ -224,11 +226,12 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
         const int p = i / OW, oo = i - p * OW;
         const h8 v = *(const h8*)(tile + (size_t)p * CW + (oo << 3));
         h8 r;
+        const f32x4 sc0 = *(const f32x4*)(scale + (oo << 3)), sc1 = *(const f32x4*)(scale + (oo << 3) + 4);
+        const f32x4 sh0 = *(const f32x4*)(shift + (oo << 3)), sh1 = *(const f32x4*)(shift + (oo << 3) + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = (oo << 3) + e;
-            float f = (float)v[e] * scale[c] + shift[c];
-            if (silu) f = f / (1.0f + __expf(-f));
+            float f = (float)v[e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+            if (silu) f = silu_f(f);
             r[e] = (half_t)f;
         }
         *(h8*)(out + ((size_t)b * HW + p) * C + c_lo + (oo << 3)) = r;
@@ -243,7 +246,7 @@ size_t groupnorm_ws_floats(int B, int HW) {
 int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, half_t* out, float* ws, hipStream_t s) {
     const int C = C0 + C1;
-    if ((C & 31) || (C0 & 7) || (C1 & 7) || C > 4096 || B <= 0 || HW <= 0) return FGDM_ERR_ARG;
+    if ((C & 31) || (C0 & 7) || (C1 & 7) || C > 4096 || B <= 0 || HW <= 0 || (size_t)HW * (C >> 3) >= (1u << 31)) return FGDM_ERR_ARG;
     // single-kernel path when NG whole groups of one sample fit in LDS
     {
         const int cpg = C >> 5;
