@@ -163,8 +163,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 
     load_tile(0, Tk < 64);
     store_tile(std::integral_constant<int, 0>{});
-    auto tile = [&](int k0, auto curc) {
+    // NSUB = 1: the tile's second 32-key sub-tile lies entirely beyond Tk (cross-attention: 77 keys = 64 + 13) and is skipped --
+    // its QK^T and PV MFMAs, its 16 exponentials per lane, its fragment reads
+    auto tile = [&](int k0, auto curc, auto nsubc) {
         constexpr int cur = decltype(curc)::value;
+        constexpr int NSUB = decltype(nsubc)::value;
         const bool more = k0 + 64 < Tk;
         if (more) load_tile(k0 + 64, k0 + 128 > Tk);      // global loads fly while this tile is computed
         __syncthreads();                   // buffer `cur` is complete; buffer cur^1 is no longer read by anyone
@@ -176,13 +179,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         // tile (the ISA of the previous version: ds_read_b128, s_waitcnt lgkmcnt(0), v_mfma ... six times over).
         h8 kf[2][NKS];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int s = 0; s < NKS; ++s) kf[sub][s] = *(const h8*)(Ks + kfrag + sub * 32 * KS + 16 * s * 2);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 sacc[2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
 #pragma unroll
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         // while the softmax below keeps the VALU busy, so the PV MFMAs start without an LDS round trip
         h4 v0f[2][2][DT], v1f[2][2][DT];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         __builtin_amdgcn_sched_barrier(0);
         if (k0 + 64 > Tk) {   // ragged last tile: keys >= Tk get -inf
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -216,9 +219,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         float psum = 0.f;
         if constexpr (FOLD) {
             // scores arrive as s log2(e) d^-1/2 - m_run; mx is therefore relative to the running max
-            float mx = fmaxf(sacc[0][0], sacc[1][0]);
+            float mx = sacc[0][0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+            if constexpr (NSUB == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const bool first = (k0 == 0);
             if (first || !__all(mx <= ATT_THR)) {
@@ -232,19 +239,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sacc[sub][r] += delta;   // this tile was taken against the old offset
                 if (lh == PH) qf[PS][0] = (half_t)(-m_hat);
             }
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[sub][r] = __builtin_amdgcn_exp2f(sacc[sub][r]);
         } else {
-        float mx = fmaxf(sacc[0][0], sacc[1][0]);
+        float mx = sacc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+        if constexpr (NSUB == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2e;
         // raise the running max only when some query of this wave outgrew it by more than ATT_THR (deferred rescale)
         if (!__all(mx - m_run <= ATT_THR)) {
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
                 for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
         }
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(sacc[sub][r] * sl2e - m_run);
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 
         // ---- O^T += Vt P^T   (with ONES: row D of O^T accumulates sum_k p)
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 h8 pf;
@@ -286,9 +297,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         }
         if (more) store_tile(std::integral_constant<int, cur ^ 1>{});     // safe: everyone passed this iteration's barrier after reading cur^1
     };
+    using one_t = std::integral_constant<int, 1>;
+    using two_t = std::integral_constant<int, 2>;
     for (int k0 = 0; k0 < Tk; k0 += 128) {
-        tile(k0, std::integral_constant<int, 0>{});
-        if (k0 + 64 < Tk) tile(k0 + 64, std::integral_constant<int, 1>{});
+        if (k0 + 32 >= Tk) tile(k0, std::integral_constant<int, 0>{}, one_t{});
+        else tile(k0, std::integral_constant<int, 0>{}, two_t{});
+        if (k0 + 64 < Tk) {
+            if (k0 + 96 >= Tk) tile(k0 + 64, std::integral_constant<int, 1>{}, one_t{});
+            else tile(k0 + 64, std::integral_constant<int, 1>{}, two_t{});
+        }
     }
 
     float l_tot;

@@ -5,6 +5,8 @@
 // Reference semantics: GroupNorm32 (ldm/modules/diffusionmodules/util.py:223-225, eps 1e-5),
 // Normalize (ldm/modules/attention.py:76-77, eps 1e-6), nn.LayerNorm (attention.py:226-228, eps 1e-5).
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 #define GN_PIX_PER_CHUNK 64
 
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 // sample, keeps that [HW][NG * cpg] slice in LDS (<= 96 KB), so x is read from HBM once instead of twice and the second
 // launch disappears (these calls were latency-bound: 24 us for a 5 MB tensor at the 8x8 level).  Same fixed-order
 // reductions as the two-kernel path -> bitwise independent of the batch.
-__global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict__ x0, int C0,
+template <int NT>   // threads per workgroup: 256 when 3+ workgroups share a CU, 512 when one 80 KB slice owns it (memory-level parallelism)
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const half_t* __restrict__ x0, int C0,
                                                         const half_t* __restrict__ x1, int C1, int HW, int NG,
                                                         float eps, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu,
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
     const int tid = threadIdx.x;
     half_t* tile = (half_t*)gsm;                                   // [HW][CW]
     float* red = (float*)(gsm + (size_t)HW * CW * 2);              // [PI][CW][2]
-    const int PI = 256 / OW;                                       // pixel lanes (OW <= 40)
+    const int PI = NT / OW;                                        // pixel lanes (OW <= 40)
     float* stats = red + (size_t)PI * CW * 2;                      // [NG][2]
     float* scale = stats + 8;                                      // [CW], then shift [CW]
     float* shift = scale + CW;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
     }
     __syncthreads();
     // two-level fixed-order reduction: per channel over the pixel lanes (all threads), then per group over its channels
-    for (int i = tid; i < 2 * CW; i += 256) {
+    for (int i = tid; i < 2 * CW; i += NT) {
         float acc = 0.f;
         for (int l = 0; l < PI; ++l) acc += red[(size_t)l * CW * 2 + i];
         red[i] = acc;                                              // lane-0 row now holds the per-channel totals
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
         stats[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
-    for (int c = tid; c < CW; c += 256) {
+    for (int c = tid; c < CW; c += NT) {
         const int g = c / cpg;
         const float w = gamma[c_lo + c] * stats[2 * g + 1];
         scale[c] = w;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
     }
     __syncthreads();
     const int total = HW * OW;
-    for (int i = tid; i < total; i += 256) {
+    for (int i = tid; i < total; i += NT) {
         const int p = i / OW, oo = i - p * OW;
         const h8 v = *(const h8*)(tile + (size_t)p * CW + (oo << 3));
         h8 r;
@@ -250,22 +253,30 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
     // single-kernel path when NG whole groups of one sample fit in LDS
     {
         const int cpg = C >> 5;
-        // first choice: slices of <= 40 KB (3+ workgroups per CU overlap their load / apply phases), else up to 96 KB
+        // first choice: slices of <= 40 KB (3+ workgroups per CU overlap their load / apply phases), else up to 64 KB (two per
+        // CU).  Fatter slices (82 KB at the 32x32 level: one workgroup per CU, its load, reduce and store phases back to back)
+        // measured 37.5 us for an 84 MB pass where the two-kernel path below moves 126 MB in about 25
+        static const int max_kb = getenv("FGDM_GN_FUSED_MAXKB") ? atoi(getenv("FGDM_GN_FUSED_MAXKB")) : 64;      // tuning knob
         for (int pass = 0; pass < 2; ++pass)
         for (int NG = 4; NG >= 1; NG >>= 1) {
             const int CW = NG * cpg;
             const size_t slice = (size_t)HW * CW * 2;
-            if ((CW & 7) || CW > 320 || slice > (pass == 0 ? 40 : 96) * 1024) continue;
-            const int OW = CW >> 3, PI = 256 / OW;
+            if ((CW & 7) || CW > 320 || slice > (size_t)std::min(pass == 0 ? 40 : 64, max_kb) * 1024) continue;
+            const int NT = slice > 40 * 1024 ? 512 : 256;      // one fat slice per CU: twice the threads (and loads in flight)
+            const int OW = CW >> 3, PI = NT / OW;
             const size_t smem = slice + ((size_t)PI * CW * 2 + 8 + 2 * (size_t)CW) * sizeof(float);
+            if (smem > 150 * 1024) continue;
             static bool attr_set = false;
             if (!attr_set) {
-                if (hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                if (hipFuncSetAttribute((const void*)gn_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_fused_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
                     return FGDM_ERR_HIP;
                 attr_set = true;
             }
-            hipLaunchKernelGGL(gn_fused_kernel, dim3(32 / NG, B), dim3(256), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma, beta,
-                               silu, out);
+            if (NT == 512) hipLaunchKernelGGL(gn_fused_kernel<512>, dim3(32 / NG, B), dim3(512), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma,
+                                              beta, silu, out);
+            else hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(32 / NG, B), dim3(256), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma, beta,
+                                    silu, out);
             return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
         }
     }
