@@ -140,7 +140,11 @@ def test_linear_variants(lib):
 
 
 GN_CASES = [(2, 64, 320, 0, 1e-5, 1), (2, 64, 1280, 640, 1e-5, 1), (1, 16, 1280, 1280, 1e-5, 1),
-            (2, 1, 1280, 0, 1e-6, 0), (3, 4096, 320, 0, 1e-6, 0), (2, 256, 640, 320, 1e-5, 1)]
+            (2, 1, 1280, 0, 1e-6, 0), (3, 4096, 320, 0, 1e-6, 0), (2, 256, 640, 320, 1e-5, 1),
+            # 82 KB slices (two-kernel path since round 2), a 41 KB slice (single kernel, second choice), ragged pixel counts,
+            # the autoencoder's 128-channel full-resolution level (4 channels per group)
+            (2, 1024, 640, 0, 1e-5, 1), (2, 1024, 1280, 0, 1e-5, 1), (1, 256, 1280, 1280, 1e-5, 1),
+            (1, 1000, 320, 0, 1e-5, 1), (1, 999, 640, 640, 1e-6, 0), (1, 16384, 128, 0, 1e-6, 1)]
 
 
 @pytest.mark.parametrize('case', GN_CASES, ids=[f'B{c[0]}_HW{c[1]}_C{c[2]}+{c[3]}' for c in GN_CASES])
@@ -186,7 +190,9 @@ def test_layernorm(lib, C_):
 
 ATT_CASES = [(2, 8, 64, 64, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160),
              (2, 8, 64, 77, 40), (1, 8, 4096, 77, 40), (2, 8, 256, 77, 160), (2, 8, 1, 1, 160), (2, 8, 16, 16, 80),
-             (1, 4, 200, 130, 80)]
+             (1, 4, 200, 130, 80),
+             # the half-tile boundary of the last key tile (second 32-key sub-tile skipped when it starts at or beyond Tk)
+             (1, 8, 64, 32, 40), (1, 8, 64, 33, 80), (1, 8, 128, 96, 40), (1, 8, 128, 97, 160)]
 
 
 @pytest.mark.parametrize('case', ATT_CASES, ids=[f'B{c[0]}_H{c[1]}_T{c[2]}_Tk{c[3]}_d{c[4]}' for c in ATT_CASES])
