@@ -352,7 +352,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 // read in slots 2j+2 (A) and 2j+3 (B), each wave writes its share of it in its own X phase -- A in X(j) (slot 2j+1), B in
 // X(j-1) (slot 2j) -- which is after the last read of p(j-2) (slot 2j-1) and before the first read of p(j).  Every wave
 // executes the same number of barriers (B one extra at the start, A one extra at the end).
-// Measured and rejected: s_setprio 1 / 2 around the matrix slot (d = 40: 649 -> 608 TF/s, d = 80: 581 -> 592).
+// Measured and rejected: s_setprio 1 / 2 around the matrix slot (d = 40: 649 -> 608 TF/s, d = 80: 581 -> 592); 64 queries per
+// wave (two 32-query blocks share every K / V^T fragment read and every barrier; 194 VGPRs, one workgroup per CU): 651 -> 657 TF/s
+// at B = 32, 633 -> 627 at B = 16 -- LDS traffic and barrier count are not what holds this kernel.
 template <int D>
 __global__ __launch_bounds__(512) void attn_pp_kernel(const half_t* __restrict__ Q, int ldq,
                                                       const half_t* __restrict__ K, int ldk,
