@@ -355,6 +355,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 // Measured and rejected: s_setprio 1 / 2 around the matrix slot (d = 40: 649 -> 608 TF/s, d = 80: 581 -> 592); 64 queries per
 // wave (two 32-query blocks share every K / V^T fragment read and every barrier; 194 VGPRs, one workgroup per CU): 651 -> 657 TF/s
 // at B = 32, 633 -> 627 at B = 16 -- LDS traffic and barrier count are not what holds this kernel.
+// Also built (round 2): a software-pipelined four-wave kernel in which ONE wave overlaps, per tile k, exp2 / pack of S(k) with
+// the MFMAs of P V (k-1) and Q K^T (k+1), the order pinned with __builtin_amdgcn_sched_group_barrier (the ISA does show
+// "MFMA, 2 v_exp" eight times and "MFMA, 3 v_exp" six times per tile; first / last iterations and the rare rescale path as
+// separate instantiations so that the region is one basic block).  Parity green, but two score tiles + two probability tiles +
+// prefetch registers need ~290 VGPRs: 256 + AGPR copies, 2 waves per SIMD, 415 TF/s against 646.  The measured picture of the
+// kernels above -- wave-tile time = MFMA cycles (448) + vector-ALU cycles (~580), i.e. no overlap at all -- is what such a
+// kernel has to beat; it needs the register allocation done by hand (the guide's one-wave-per-SIMD assembly loop).
 template <int D>
 __global__ __launch_bounds__(512) void attn_pp_kernel(const half_t* __restrict__ Q, int ldq,
                                                       const half_t* __restrict__ K, int ldk,
