@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 // Measured and rejected: s_setprio 1 / 2 around the matrix slot (d = 40: 649 -> 608 TF/s, d = 80: 581 -> 592); 64 queries per
 // wave (two 32-query blocks share every K / V^T fragment read and every barrier; 194 VGPRs, one workgroup per CU): 651 -> 657 TF/s
 // at B = 32, 633 -> 627 at B = 16 -- LDS traffic and barrier count are not what holds this kernel.
+// Compiler scheduling strategies for this file (-mllvm -amdgpu-sched-strategy=max-ilp / iterative-ilp): 641 -> 415 / 645 TF/s.
 // Also built (round 2): a software-pipelined four-wave kernel in which ONE wave overlaps, per tile k, exp2 / pack of S(k) with
 // the MFMAs of P V (k-1) and Q K^T (k+1), the order pinned with __builtin_amdgcn_sched_group_barrier (the ISA does show
 // "MFMA, 2 v_exp" eight times and "MFMA, 3 v_exp" six times per tile; first / last iterations and the rare rescale path as
