@@ -252,6 +252,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     //   round 2: stages issued in PAIRS every other K-step (the two 64-byte halves of the same 128-byte lines back to back, so
     //     that the second half hits the line in L1 instead of fetching it from L2 again): -3..-15 % on every shape
     //   round 2: five-stage ring for the 128x320 tile (143 KB): -1..-2 %
+    //   round 2: half of the first wave of workgroups started 4 / 8 / 12 us late (load and store phases of the two halves of the
+    //     chip out of step): L0 320->320 58 -> 59 / 60 / 64 us -- the phases of the CUs are not what limits the short-K linears
     //   round 2: TWO 4-wave workgroups per CU (128x320 / 128x256 tiles, 2-stage ring, 66 KB LDS each) for the short-K
     //     linears, so that one workgroup's store-bound epilogue overlaps the other's operand stream: L0 320->320 65 vs 66 us,
     //     qk 320->640 116 vs 111, GEGLU 320->2560 427 vs 421 -- no gain; these layers sit at ~3.9 TB/s of HBM traffic either way
