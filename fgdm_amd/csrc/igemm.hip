@@ -320,7 +320,8 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 static int g_force_cfg = 0;
 void igemm_set_force_cfg(int cfg) { g_force_cfg = cfg; }
 
-// tile configuration for `a` (0 = the 2-stage kernel picks one of its own tiles; 4..10 = pipelined kernel cfg 0..6)
+// tile configuration for `a` (0 = the 2-stage kernel picks one of its own tiles; 4 + c = pipelined kernel cfg c: tile c & 15 =
+// 0..6, K loop c >> 4, see igemm2_launch)
 static int pick_force(const IgemmArgs& a) {
     int force = a.force_cfg ? a.force_cfg : g_force_cfg;
     if (a.act == ACT_QGELU) {                   // the pipelined kernel's epilogue does not carry quick-GELU (text encoder only)
@@ -353,7 +354,9 @@ static int pick_force(const IgemmArgs& a) {
 int igemm_stats_slots(const IgemmArgs& a) {
     if (a.out_kind != OUT_F16 || a.act == ACT_GEGLU || a.splitk > 1 || (a.N % 320) || (a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return 0;
     const int f = pick_force(a);
-    return (f == 4 || f == 6 || f == 7 || f == 9) ? a.N / 160 : 0;
+    if (f < 4) return 0;
+    const int tile = (f - 4) & 15;
+    return (tile == 0 || tile == 2 || tile == 3 || tile == 5) ? a.N / 160 : 0;
 }
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s) {

@@ -30,6 +30,14 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_addr) {
                  : "v"(g), "s"(lds_wave_addr)
                  : "memory");
 }
+// the same for the pipelined K loop, whose instruction stream is what bounds it: M0 is written and not restored (nothing else in
+// these kernels uses it: LDS instructions take no M0 on gfx9+), and the weight pieces use the SGPR-base + 32-bit VGPR offset form
+__device__ __forceinline__ void glds16_m0(const void* g, unsigned lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_addr) : "memory");
+}
+__device__ __forceinline__ void glds16_sv(unsigned voff, const void* sbase, unsigned lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_addr) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const void*)p; }
 // rstd (acc - mean u): one fma and one multiply as inline asm -- with -ffp-contract=fast the backend fuses a multiply into the
 // bias add that follows whatever the source says; the 2-stage kernel (igemm.hip) rounds in exactly this sequence, and WHICH
@@ -56,7 +64,9 @@ constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (m
 // than random ones), measured +3..9 % on the conv shapes (tools/bench_igemm.py cfg 4 vs 7).
 // LN: the consumer side of a folded LayerNorm (IgemmArgs::ln_stats) is its own instantiation, so every other layer pays nothing
 // for it (as a run-time branch inside the register stage it cost the 256x320 tile 208 bytes of scratch per lane)
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH>
+// PIPE: 0 = every K-step reads its 14 fragments, then runs its 40 MFMAs (all eight waves in the same phase); 1 = software-pipelined
+// K loop (see there).  ABL: the ablation switches of IgemmArgs::debug exist only in the instantiations tools/bench_igemm.py asks for.
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH, int PIPE, bool ABL>
 __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, T = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         a_off[i] = (s ^ swz_of(r)) << 3;                            // source-side swizzle (LDS image stays linear)
         a_pix[i] = -1; a_yx[i] = 0;
         const int m = m0 + r;
-        if (m < a.M) {
+        if (PIPE == 0 && m < a.M) {
             if (!CONV) {
                 a_pix[i] = m;
             } else {
@@ -140,34 +150,74 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         b_lds[i] = A_BYTES + idx * 1024;
     }
     const unsigned Hu = (unsigned)(a.H << up), Wu = (unsigned)(a.W << up);
+    // ... and the form the pipelined loop uses (stride 1 / 2; the launcher keeps UP2 and tensors >= 4 GB on the loop above): byte
+    // offset of the slot's centre pixel in either source, and one validity bit per tap -- a piece's address is then
+    // (source + tap / channel displacement: scalar) + offset, or the zero page
+    unsigned a_b0[LA], a_b1[LA], a_msk[LA], b_b[LB];
+    if constexpr (PIPE != 0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            a_b0[i] = a_b1[i] = a_msk[i] = 0;
+            const int q = (wave + i * NW) * 64 + lane, r = q >> 2;
+            const int m = m0 + r;
+            if (m < a.M) {
+                unsigned cen = (unsigned)m;
+                a_msk[i] = 1;
+                if (CONV) {
+                    const int hw = a.Ho * a.Wo;
+                    const int b = m / hw, rem = m - b * hw;
+                    const int oy = (rem / a.Wo) * sy, ox = (rem - (rem / a.Wo) * a.Wo) * sy;
+                    cen = (unsigned)(b * a.H * a.W + oy * a.W + ox);
+                    unsigned msk = 0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int uy = oy + t / 3 - 1, ux = ox + t % 3 - 1;
+                        if ((unsigned)uy < (unsigned)a.H && (unsigned)ux < (unsigned)a.W) msk |= 1u << t;
+                    }
+                    a_msk[i] = msk;
+                }
+                a_b0[i] = (cen * (unsigned)a.C0 + (unsigned)a_off[i]) * 2u;
+                a_b1[i] = (cen * (unsigned)a.C1 + (unsigned)a_off[i]) * 2u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) b_b[i] = (unsigned)b_off[i] * 2u;
+    }
 
     // K-step order (CONV): 64-channel chunk outermost, then the 9 taps, then the two 32-channel halves -- so the nine
     // shifted re-reads of a (pixel, channel-chunk) happen in consecutive steps and hit L1/L2 instead of travelling
     // to the Infinity Cache (the LDS fill path, ~70 GB/s per CU from L2 vs ~33 from MALL, is what bounds this
     // kernel).  `cc` = channel offset of the step, `tap` = 0..8.  Weights are packed in the same order.
-    auto stage = [&](int kt, int tap, int cc, int buf) {
+    // piece p of a stage: p < LA = this wave's A slot p, else its B slot p - LA (one 1 KiB LDS-DMA wave-instruction each)
+    auto stage_piece = [&](int kt, int tap, int cc, int buf, int p) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(smem) + buf * STAGE_BYTES);
-        const half_t* src = a.A0;
-        int Cs = a.C0, co = cc;
-        if (co >= a.C0) { src = a.A1; Cs = a.C1; co -= a.C0; }
-        const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const half_t* p = a.zero;
+        if (p < LA) {
+            const int i = p;
+            const half_t* src = a.A0;
+            int Cs = a.C0, co = cc;
+            if (co >= a.C0) { src = a.A1; Cs = a.C1; co -= a.C0; }
+            const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
+            const half_t* ptr = a.zero;
             if (!CONV) {
-                if (a_pix[i] >= 0) p = src + (size_t)a_pix[i] * Cs + co + a_off[i];
+                if (a_pix[i] >= 0) ptr = src + (size_t)a_pix[i] * Cs + co + a_off[i];
             } else {
                 // one formula for stride 1 / stride 2 / conv over the nearest-2x-upsampled image
                 const int uy = (a_yx[i] >> 16) + ky, ux = (a_yx[i] & 0xffff) + kx;
                 if (a_pix[i] >= 0 && (unsigned)uy < Hu && (unsigned)ux < Wu)
-                    p = src + (size_t)(a_pix[i] + (uy >> up) * a.W + (ux >> up)) * Cs + co + a_off[i];
+                    ptr = src + (size_t)(a_pix[i] + (uy >> up) * a.W + (ux >> up)) * Cs + co + a_off[i];
             }
-            if (a.debug & 8) p = a.zero;                 // ablation: same instruction stream, no memory footprint
-            glds16(p, base + (wave + i * NW) * 1024);
+            if constexpr (ABL) { if (a.debug & 8) ptr = a.zero; }     // ablation: same instruction stream, no memory footprint
+            glds16(ptr, base + (wave + i * NW) * 1024);
+        } else {
+            const int i = p - LA;
+            const half_t* ptr = a.Wt + (size_t)b_off[i] + ((size_t)(k_begin + kt) << 5);
+            if constexpr (ABL) { if (a.debug & 8) ptr = a.zero; }
+            glds16(ptr, base + b_lds[i]);
         }
+    };
+    auto stage = [&](int kt, int tap, int cc, int buf) {
 #pragma unroll
-        for (int i = 0; i < LB; ++i)
-            glds16((a.debug & 8) ? a.zero : a.Wt + (size_t)b_off[i] + ((size_t)(k_begin + kt) << 5), base + b_lds[i]);
+        for (int p = 0; p < LPS; ++p) stage_piece(kt, tap, cc, buf, p);
     };
 
     // accumulators, TRANSPOSED: acc[nj][mi] = W-tile(nj) x X-tile(mi)^T ; row = channel, lane column = pixel
@@ -197,9 +247,52 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
             cc += 32;
         }
     };
+    // the pipelined loop's form of a stage: (tap, cc) -> ONE scalar displacement; a piece = base + precomputed offset, or zeros
+    struct StageSc { const char* sbase; const char* wbase; unsigned lbase; bool s1; int tap; };
+    auto stage_scalars = [&](int kn, int tap, int cc) {
+        StageSc sc;
+        sc.s1 = cc >= a.C0;                                   // second source of a virtual concat
+        const half_t* src = sc.s1 ? a.A1 : a.A0;
+        const int Cs = sc.s1 ? a.C1 : a.C0;
+        int disp = sc.s1 ? cc - a.C0 : cc;                    // halfs: channel offset (+ the tap's pixel displacement)
+        if (CONV) disp += ((tap / 3 - 1) * a.W + (tap - (tap / 3) * 3 - 1)) * Cs;
+        sc.sbase = (const char*)src + (ptrdiff_t)disp * 2;
+        sc.wbase = (const char*)a.Wt + ((size_t)(k_begin + kn) << 6);
+        sc.lbase = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (kn & 3) * STAGE_BYTES);
+        sc.tap = tap;
+        return sc;
+    };
+    auto lean_piece = [&](const StageSc& sc, int p) {
+        bool zsrc = false;
+        if constexpr (ABL) zsrc = (a.debug & 8) != 0;
+        if (p < LA) {
+            const unsigned off = sc.s1 ? a_b1[p] : a_b0[p];
+            const char* ptr = ((a_msk[p] >> sc.tap) & 1) ? sc.sbase + off : (const char*)a.zero;
+            if constexpr (ABL) { if (zsrc) ptr = (const char*)a.zero; }
+            glds16_m0(ptr, sc.lbase + (wave + p * NW) * 1024);
+        } else if (ABL && zsrc) {
+            glds16_m0(a.zero, sc.lbase + b_lds[p - LA]);
+        } else {
+            glds16_sv(b_b[p - LA], sc.wbase, sc.lbase + b_lds[p - LA]);
+        }
+    };
+    auto advance_bf = [&]() {       // the same walk as advance(), branch-free
+        if (!CONV) { cc += 32; return; }
+        const bool second = (cc & 32) != 0, wrap = second && tap == 8;
+        cc = second ? (wrap ? cc + 32 : cc - 32) : cc + 32;
+        tap = second ? (wrap ? 0 : tap + 1) : tap;
+    };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
-        if (s < nk) { stage(s, tap, cc, s); advance(); }
+        if (s < nk) {
+            if constexpr (PIPE == 0) { stage(s, tap, cc, s); advance(); }
+            else {
+                const StageSc sc = stage_scalars(s, tap, cc);
+#pragma unroll
+                for (int pp = 0; pp < LPS; ++pp) lean_piece(sc, pp);
+                advance_bf();
+            }
+        }
     }
 
     // ---- epilogue operands (bias, per-sample emb rows) into LDS now, so the epilogue never waits on global loads
@@ -237,60 +330,126 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         }
 
     // ---- K loop: one stage (BK = 32) and ONE barrier per iteration; STAGES-1 stages of loads in flight.
-    // Tried and measured on MI355X (tools/bench_igemm.py, L0 conv 320->320, 256x320 tile):
-    //   all 14 fragment reads hoisted ahead of one 20-MFMA cluster with counted lgkmcnt waits (this version)  779 TF/s
-    //   reads of the next half-stage issued under the MFMAs of the current one (barrier mid-stage)             685 TF/s
-    //   wave groups 0-3 / 4-7 staggered by one barrier phase (2 barriers per stage)                           734 TF/s
-    //   SIMD-mate waves (w, w+4) refill at different points (after the barrier / after MFMA 10 of 20)          -3..-7 %
-    //   two K-steps per barrier (all DMAs of a stage pair must have landed at one wait)                         -8 %
-    //   full stagger, re-measured on the 16x16x32 kernel incl. all-zero operands (no power limit) and on the
-    //     half-empty grids of the 16x16 level: SIMD-mates half a K-step apart, one mate refills + reads fragments
-    //     while the other runs its 40 MFMAs, 2 barriers per step: -10 % (256x320), -15..-25 % (128x320): the
-    //     refill + fragment-read phase is LONGER than the MFMA phase, so pairing them does not hide it
-    //     (the stagger lifts the no-global-load ablation from 1044 to 1187 TF/s but loses it again to the LDS-DMA
-    //      fill path: 207 us compute-only, +46 us for the load instructions alone, +76 us for their memory traffic)
-    //   round 2: stages issued in PAIRS every other K-step (the two 64-byte halves of the same 128-byte lines back to back, so
-    //     that the second half hits the line in L1 instead of fetching it from L2 again): -3..-15 % on every shape
-    //   round 2: five-stage ring for the 128x320 tile (143 KB): -1..-2 %
-    //   round 2: half of the first wave of workgroups started 4 / 8 / 12 us late (load and store phases of the two halves of the
-    //     chip out of step): L0 320->320 58 -> 59 / 60 / 64 us -- the phases of the CUs are not what limits the short-K linears
-    //   round 2: TWO 4-wave workgroups per CU (128x320 / 128x256 tiles, 2-stage ring, 66 KB LDS each) for the short-K
-    //     linears, so that one workgroup's store-bound epilogue overlaps the other's operand stream: L0 320->320 65 vs 66 us,
-    //     qk 320->640 116 vs 111, GEGLU 320->2560 427 vs 421 -- no gain; these layers sit at ~3.9 TB/s of HBM traffic either way
-    auto wait_stage = [&](int k_needed) {     // stage k_needed landed; younger stages of this wave may stay in flight
-        const int younger = min(nk - 1 - k_needed, STAGES - 2);
-        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LPS>();
-        else if (STAGES >= 3 && younger == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
-    };
-    for (int kt = 0; kt < nk; ++kt) {
-        wait_stage(kt);
-        // my fragment reads of step kt-1 are done (WAR below).  The BUILTIN form (0xC07F = lgkmcnt(0) only) is modelled by
-        // hipcc's wait-count pass, so the ds_reads that follow get COUNTED lgkmcnt waits.
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        // every wave's part of stage kt is in LDS, and nobody still reads buffer (kt-1) % STAGES: refill it
-        if (kt + STAGES - 1 < nk && !(a.debug & 1)) { stage(kt + STAGES - 1, tap, cc, (kt + STAGES - 1) % STAGES); advance(); }
-        const char* As = smem + (kt % STAGES) * STAGE_BYTES + (wm * TM) * ROWB;
-        const char* Bs = smem + (kt % STAGES) * STAGE_BYTES + A_BYTES + (wn * TN) * ROWB;
-        h8 xf[KS][MI], wf[KS][NI];
+    // (what was tried on the way and rejected: DESIGN.md section 4.1 / 4.2)
+    if constexpr (PIPE == 0) {
+        auto wait_stage = [&](int k_needed) {     // stage k_needed landed; younger stages of this wave may stay in flight
+            const int younger = min(nk - 1 - k_needed, STAGES - 2);
+            if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LPS>();
+            else if (STAGES >= 3 && younger == 1) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
+        };
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_stage(kt);
+            // my fragment reads of step kt-1 are done (WAR below).  The BUILTIN form (0xC07F = lgkmcnt(0) only) is modelled by
+            // hipcc's wait-count pass, so the ds_reads that follow get COUNTED lgkmcnt waits.
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            // every wave's part of stage kt is in LDS, and nobody still reads buffer (kt-1) % STAGES: refill it
+            bool refill = kt + STAGES - 1 < nk;
+            if constexpr (ABL) refill = refill && !(a.debug & 1);
+            if (refill) { stage(kt + STAGES - 1, tap, cc, (kt + STAGES - 1) % STAGES); advance(); }
+            const char* As = smem + (kt % STAGES) * STAGE_BYTES + (wm * TM) * ROWB;
+            const char* Bs = smem + (kt % STAGES) * STAGE_BYTES + A_BYTES + (wn * TN) * ROWB;
+            h8 xf[KS][MI], wf[KS][NI];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {     // read order = MFMA consumption order
+            for (int ks = 0; ks < KS; ++ks) {     // read order = MFMA consumption order
 #pragma unroll
-            for (int i = 0; i < MI; ++i) xf[ks][i] = *(const h8*)(As + i * MS * ROWB + koff[ks]);
+                for (int i = 0; i < MI; ++i) xf[ks][i] = *(const h8*)(As + i * MS * ROWB + koff[ks]);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) wf[ks][j] = *(const h8*)(Bs + j * MS * ROWB + koff[ks]);
+                for (int j = 0; j < NI; ++j) wf[ks][j] = *(const h8*)(Bs + j * MS * ROWB + koff[ks]);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep all reads ahead of the MFMA cluster
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        if constexpr (MS == 32) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
+                        else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
+                    }
         }
-        __builtin_amdgcn_sched_barrier(0);     // keep all reads ahead of the MFMA cluster
+    } else {
+        // Software-pipelined K loop.  In the loop above all eight waves sit in the same phase: after the barrier they all issue
+        // LDS-DMAs, then all read fragments (the LDS array saturated, the matrix pipes idle), then all run MFMAs (the LDS idle);
+        // a K-step took ~2600 cycles against 1280 of MFMA work per SIMD.  Here a wave's stream is its MFMAs with everything else
+        // between them: step kt is NI groups of MI MFMAs (one W fragment against the MI X fragments), and group j also
+        //   * reads W fragment j + WD of the step into a register ring (the first WD of step kt + 1 at the end),
+        //   * reads its share of the MI X fragments of step kt + 1 into the other half of a double buffer,
+        //   * issues its share of the LPS LDS-DMA pieces of stage kt + STAGES - 1,
+        // so after the barrier a wave's first MFMA has its operands in registers, and the DMA requests reach the fill path
+        // (L2 -> LDS, ~70 GB/s per CU: as long as the MFMAs of a 256x320 step at the clock this kernel holds) evenly spread.
+        // Reads of stage kt + 1 happen during step kt, so the barrier of step kt is the one behind which stage kt + 1 has
+        // landed: one stage fewer in flight across it than in the loop above.  WAR: buffer (kt - 1) % STAGES is refilled
+        // during step kt; its last reads fed MFMAs of step kt - 1, all issued before the barrier of step kt.
+        static_assert(MS == 16 && STAGES == 4, "pipelined loop: 16x16x32 MFMA, four-stage ring");
+        constexpr int RW = NI % 5 == 0 ? 5 : 4;        // W ring slots; NI % RW == 0 keeps the slot of (step, j) static
+        constexpr int WD = 3;                          // ... and W fragment j + WD is requested in group j
+        static_assert(NI % RW == 0 && WD < RW && NI >= RW, "W ring");
+        auto rdX = [&](int kt, int i) { return *(const h8*)(smem + (kt & 3) * STAGE_BYTES + (wm * TM + i * MS) * ROWB + koff[0]); };
+        auto rdW = [&](int kt, int j) { return *(const h8*)(smem + (kt & 3) * STAGE_BYTES + A_BYTES + (wn * TN + j * MS) * ROWB + koff[0]); };
+        h8 xa[MI], xb[MI], wr[RW];
+        {   // stage 0 landed (everybody's part of it) -> first fragments
+            const int younger = min(nk - 1, STAGES - 2);
+            if (younger >= 2) wait_vmcnt<2 * LPS>(); else if (younger == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+            for (int i = 0; i < MI; ++i) xa[i] = rdX(0, i);
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+            for (int d = 0; d < WD; ++d) wr[d] = rdW(0, d);
+        }
+        // What bounds this loop is its instruction stream next to the MFMAs (MI355X under load: the scalar and vector ALU work of
+        // the LDS-DMA addressing, ~90 SALU + 50 VALU per wave and step in the first version, cost a third of the step), so:
+        // per-slot byte offsets and tap-validity masks are precomputed, a stage's displacement is ONE scalar, the tap / channel
+        // walk is branch-free, the weight pieces take the SGPR-base form, M0 is not saved, and the steps that refill (all but
+        // the last STAGES - 1) are their own instantiation of the step, so nothing in them is conditional.
+        auto step = [&](auto RF, int kt, h8 (&cur)[MI], h8 (&nxt)[MI]) {
+            constexpr bool REFILL = decltype(RF)::value;
+            // my pieces of stage kt + 1 landed (kt + 2 may fly; it exists in every refilling step)
+            if (REFILL || kt + 2 < nk) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            // the fragments requested at the end of the last step: waited for HERE (the builtin form: hipcc's wait-count pass
+            // then knows that nothing is pending and counts the waits of this step exactly; across the loop edge it assumed
+            // lgkmcnt(0) in front of the first MFMA, i.e. behind the reads group 0 has just issued)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            const StageSc sc = stage_scalars(kt + STAGES - 1, tap, cc);
+            bool refill = REFILL;
+            if constexpr (ABL) refill = refill && !(a.debug & 1);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    if constexpr (MS == 32) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
-                    else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[j][i], 0, 0, 0);
+            for (int j = 0; j < NI; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (REFILL) {
+#pragma unroll
+                    for (int p = 0; p < LPS; ++p)
+                        if (p * NI / LPS == j && (!ABL || refill)) lean_piece(sc, p);
                 }
+                { const int jn = j + WD; wr[jn % RW] = jn < NI ? rdW(kt, jn) : rdW(kt + 1, jn - NI); }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    if (i * NI / MI == j) nxt[i] = rdX(kt + 1, i);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j % RW], cur[i], acc[j][i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (REFILL) advance_bf();
+        };
+        const int nr = max(nk - (STAGES - 1), 0);        // steps that refill
+        int kt = 0;
+        for (; kt + 1 < nr; kt += 2) {
+            step(std::true_type{}, kt, xa, xb);
+            step(std::true_type{}, kt + 1, xb, xa);
+        }
+        if (kt < nr) {                                   // odd count: one more, then the fragment double buffer changes sides
+            step(std::true_type{}, kt, xa, xb);
+            ++kt;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xa[i] = xb[i];
+        }
+        if (kt < nk) step(std::false_type{}, kt, xa, xb);
+        if (kt + 1 < nk) step(std::false_type{}, kt + 1, xb, xa);
+        if (kt + 2 < nk) step(std::false_type{}, kt + 2, xa, xb);
+        wait_vmcnt<0>();        // (nothing is in flight here; keeps the ring provably idle for the epilogue's staging)
     }
 
     if constexpr (SPLIT) {  // split-K: raw fp32 partial tile -> ws[split][row][col]; igemm_splitk_reduce finishes the job
@@ -310,7 +469,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         }
         return;
     } else {
-    if (a.debug & 4) {      // ablation: keep the accumulators alive but skip the whole epilogue
+    if (ABL && (a.debug & 4)) {      // ablation: keep the accumulators alive but skip the whole epilogue
         float sink = 0.f;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -528,13 +687,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
     }   // !SPLIT
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH, int PIPE, bool ABL>
 int launch2p(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4 + (2 * BM + BN) * 4;      // + staged bias, emb rows, LayerNorm (mean, rstd), u
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH>;
+    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH, PIPE, ABL>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -557,28 +716,49 @@ int epilogue_path(const IgemmArgs& a) {
     if (!a.rowvec) return 1;
     return (BM - 1) / a.rows_per_sample + 2 <= RV_MAX ? 2 : 0;
 }
-// FAST: also build the specialised epilogues (the hot tile configurations); otherwise PATH 0 only
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT = false, int MS = 16, bool LN = false, bool FAST = false>
+// FAST: also build the specialised epilogues (the hot tile configurations); otherwise PATH 0 only.  The pipelined K loop exists
+// for PATH 1 / 2 (every layer of the sampling loop but a handful); the general epilogue keeps the phase-locked loop (its register
+// stage and the pipelined loop's fragment ring do not fit 256 VGPRs together).  a.debug != 0 (only tools/bench_igemm.py sets
+// it) takes the ablation instantiation: PATH 1 of the FAST non-LayerNorm tiles.
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, bool FAST, int PIPE>
 int launch2(const IgemmArgs& a, hipStream_t s) {
     static const bool fast_on = !(getenv("FGDM_IGEMM_EPI_PATHS") && atoi(getenv("FGDM_IGEMM_EPI_PATHS")) == 0);   // A/B knob
+    if constexpr (FAST && !SPLIT && !LN) {
+        if (a.debug)
+            return epilogue_path<BM, GEGLU, LN>(a) == 1 ? launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 1, PIPE, true>(a, s)
+                                                        : FGDM_ERR_ARG;
+    }
+    if (a.debug) return FGDM_ERR_ARG;
     if constexpr (FAST && !SPLIT) {
         switch (fast_on ? epilogue_path<BM, GEGLU, LN>(a) : 0) {
-            case 1: return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 1>(a, s);
-            case 2: if constexpr (!GEGLU && !LN) return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 2>(a, s);
+            case 1: return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 1, PIPE, false>(a, s);
+            case 2: if constexpr (!GEGLU && !LN) return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 2, PIPE, false>(a, s);
             default: break;
         }
     }
-    return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 0>(a, s);
+    return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 0, 0, false>(a, s);
 }
-template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU, int MS = 16>
+template <int BM, int BN, bool GEGLU, int MS, int PIPE>
 int launch2m(const IgemmArgs& a, hipStream_t s) {
-    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS, false, MS == 16>(a, s)
-                               : launch2<BM, BN, WM, WN, STAGES, true, GEGLU, false, MS, false, MS == 16>(a, s);
+    return a.mode == IG_LINEAR ? launch2<BM, BN, 4, 2, 4, false, GEGLU, false, MS, false, MS == 16, PIPE>(a, s)
+                               : launch2<BM, BN, 4, 2, 4, true, GEGLU, false, MS, false, MS == 16, PIPE>(a, s);
 }
 // consumer of a folded LayerNorm: always a LINEAR GEMM
-template <int BM, int BN, int WM, int WN, int STAGES, bool GEGLU, int MS = 16>
+template <int BM, int BN, bool GEGLU, int MS, int PIPE>
 int launch2ln(const IgemmArgs& a, hipStream_t s) {
-    return launch2<BM, BN, WM, WN, STAGES, false, GEGLU, false, MS, true, MS == 16>(a, s);
+    return launch2<BM, BN, 4, 2, 4, false, GEGLU, false, MS, true, MS == 16, PIPE>(a, s);
+}
+// one tile configuration (all: 8 waves as 4 x 2, four-stage ring), any mode
+template <int BM, int BN, int MS, int PIPE>
+int launch_tile(const IgemmArgs& a, hipStream_t s) {
+    const bool g = a.act == ACT_GEGLU;
+    if (a.ln_stats) {
+        if constexpr (BN == 256) { if (g) return launch2ln<BM, BN, true, MS, PIPE>(a, s); }
+        if constexpr (BN == 128) return FGDM_ERR_ARG;
+        else return launch2ln<BM, BN, false, MS, PIPE>(a, s);
+    }
+    if constexpr (BN == 256) { if (g) return launch2m<BM, BN, true, MS, PIPE>(a, s); }
+    return launch2m<BM, BN, false, MS, PIPE>(a, s);
 }
 
 // out[m][n] = ((sum_s ws[s][m][n]) + bias + emb -> act) * scale + resid, fixed summation order
@@ -626,39 +806,35 @@ int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
-// cfg: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320     (all: 8 waves, 4-stage ring, 16x16x32 MFMA)
-//      3..5 = the same tiles on the 32x32x16 MFMA (kept for A/B measurements: tools/bench_igemm.py cfg 7..9)
+// cfg & 15: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320   6 = 256x128   (all: 8 waves, 4-stage ring, 16x16x32 MFMA)
+//           3..5 = tiles 0..2 on the 32x32x16 MFMA (kept for A/B measurements)
+// cfg >> 4: K loop: 0 = the process default (FGDM_IGEMM_PIPE, default 1), 1 = the phase-locked loop, 2 = the software-pipelined one
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if ((a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return FGDM_ERR_ARG;
-    const int bn = (cfg == 1 || cfg == 4) ? 256 : cfg == 6 ? 128 : 320;
+    static const int pipe_default = getenv("FGDM_IGEMM_PIPE") ? atoi(getenv("FGDM_IGEMM_PIPE")) : 1;
+    const int tile = cfg & 15, psel = cfg >> 4;
+    // the pipelined loop addresses with 32-bit byte offsets and stride 1 / 2 geometry: the nearest-2x-upsampled convolutions
+    // (three per evaluation) and operands of 4 GB or more stay on the phase-locked loop
+    const size_t px = a.mode == IG_LINEAR ? (size_t)a.M : (size_t)a.B * a.H * a.W;
+    const bool small = px * (size_t)std::max(a.C0, a.C1) * 2 < (1ull << 32) && (size_t)(a.N + 320) * a.K * 2 < (1ull << 32);
+    const bool pipe = (psel == 0 ? pipe_default != 0 : psel == 2) && a.mode != IG_CONV3_UP2 && small;
+    const int bn = (tile == 1 || tile == 4) ? 256 : tile == 6 ? 128 : 320;
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
-    const bool g = a.act == ACT_GEGLU;
-    if (g && bn != 256) return FGDM_ERR_ARG;
-    if (a.splitk > 1 && cfg != 2) return FGDM_ERR_ARG;
-    if (a.ln_stats) {       // LayerNorm consumers: the LN instantiations (128x320 in place of 256x320, see igemm2_kernel)
-        if (a.mode != IG_LINEAR || a.splitk > 1) return FGDM_ERR_ARG;
-        switch (cfg) {
-            case 0: return launch2ln<256, 320, 4, 2, 4, false>(a, s);
-            case 2: return launch2ln<128, 320, 4, 2, 4, false>(a, s);
-            case 1: return g ? launch2ln<256, 256, 4, 2, 4, true>(a, s) : launch2ln<256, 256, 4, 2, 4, false>(a, s);
-            case 3: return launch2ln<256, 320, 4, 2, 4, false, 32>(a, s);
-            case 5: return launch2ln<128, 320, 4, 2, 4, false, 32>(a, s);
-            case 4: return g ? launch2ln<256, 256, 4, 2, 4, true, 32>(a, s) : launch2ln<256, 256, 4, 2, 4, false, 32>(a, s);
-            default: return FGDM_ERR_ARG;
-        }
+    if (a.act == ACT_GEGLU && bn != 256) return FGDM_ERR_ARG;
+    if (a.splitk > 1) {
+        if (tile != 2 || a.ln_stats) return FGDM_ERR_ARG;
+        return a.mode == IG_LINEAR ? launch2<128, 320, 4, 2, 4, false, false, true, 16, false, false, 0>(a, s)
+                                   : launch2<128, 320, 4, 2, 4, true, false, true, 16, false, false, 0>(a, s);
     }
-    switch (cfg) {
-        case 0: return launch2m<256, 320, 4, 2, 4, false>(a, s);
-        case 1: return g ? launch2m<256, 256, 4, 2, 4, true>(a, s) : launch2m<256, 256, 4, 2, 4, false>(a, s);
-        case 2:
-            if (a.splitk > 1)
-                return a.mode == IG_LINEAR ? launch2<128, 320, 4, 2, 4, false, false, true>(a, s)
-                                           : launch2<128, 320, 4, 2, 4, true, false, true>(a, s);
-            return launch2m<128, 320, 4, 2, 4, false>(a, s);
-        case 3: return launch2m<256, 320, 4, 2, 4, false, 32>(a, s);
-        case 4: return g ? launch2m<256, 256, 4, 2, 4, true, 32>(a, s) : launch2m<256, 256, 4, 2, 4, false, 32>(a, s);
-        case 5: return launch2m<128, 320, 4, 2, 4, false, 32>(a, s);
-        case 6: return launch2m<256, 128, 4, 2, 4, false>(a, s);        // N = 128 (the autoencoder's full-resolution level)
+    if (a.ln_stats && a.mode != IG_LINEAR) return FGDM_ERR_ARG;
+    switch (tile) {
+        case 0: return pipe ? launch_tile<256, 320, 16, 1>(a, s) : launch_tile<256, 320, 16, 0>(a, s);
+        case 1: return pipe ? launch_tile<256, 256, 16, 1>(a, s) : launch_tile<256, 256, 16, 0>(a, s);
+        case 2: return pipe ? launch_tile<128, 320, 16, 1>(a, s) : launch_tile<128, 320, 16, 0>(a, s);
+        case 3: return launch_tile<256, 320, 32, 0>(a, s);
+        case 4: return launch_tile<256, 256, 32, 0>(a, s);
+        case 5: return launch_tile<128, 320, 32, 0>(a, s);
+        case 6: return pipe ? launch_tile<256, 128, 16, 1>(a, s) : launch_tile<256, 128, 16, 0>(a, s);
         default: return FGDM_ERR_ARG;
     }
 }

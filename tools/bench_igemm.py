@@ -29,18 +29,26 @@ SHAPES = [
     ('L3 lin 1280->1280', 32, 8, 8, 1280, 0, 1280, 1, 1, 0, 0, 1),
     ('L1 down s2 320->320', 32, 64, 64, 320, 0, 320, 3, 2, 0, 0, 0),
     ('L0 up 640->640', 32, 32, 32, 640, 0, 640, 3, 1, 1, 0, 0),
+    # the same GEMMs as the L0 / L1 / L2 convolutions without the 3x3 gather (what the addressing and the tap re-reads cost)
+    ('L0 lin 2880->320', 32, 64, 64, 2880, 0, 320, 1, 1, 0, 0, 1),
+    ('L1 lin 5760->640', 32, 32, 32, 5760, 0, 640, 1, 1, 0, 0, 1),
+    ('L2 lin 11520->1280', 32, 16, 16, 11520, 0, 1280, 1, 1, 0, 0, 1),
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--cfgs', default='0,4,5,6,7,8,9')
+    ap.add_argument('--cfgs', default='0,4,5,6,7,8,9', help='force_cfg + 256 * ablation bits (IgemmArgs::debug), comma separated')
+    ap.add_argument('--shapes', default='', help='only shapes whose name contains one of these comma-separated substrings')
     a = ap.parse_args()
+    want = [w for w in a.shapes.split(',') if w]
     lib = _lib.load()
     cfgs = [int(c) for c in a.cfgs.split(',')]
-    print('shape'.ljust(26) + ''.join(f'cfg{c:>2}(TF/s us)'.rjust(18) for c in cfgs))
+    print('shape'.ljust(26) + ''.join(f'cfg{c:>4}(TF/s us)'.rjust(18) for c in cfgs))
     for name, B, H, W, C0, C1, Co, ks, st, up, act, res in SHAPES:
+        if want and not any(w in name for w in want):
+            continue
         Ho, Wo = (2 * H, 2 * W) if up else (((H - 1) // 2 + 1, (W - 1) // 2 + 1) if st == 2 else (H, W))
         flops = 2.0 * B * Ho * Wo * Co * ks * ks * (C0 + C1)
         row = name.ljust(26)
