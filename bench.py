@@ -155,6 +155,9 @@ def main():
                          'evaluation, so every layer shape is sampled uniformly); 1 = every launch')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend: nccl (= RCCL over xGMI, the product) or gloo (CPU rehearsal with --dry-run)')
+    ap.add_argument('--dump-latents', default=None,
+                    help='after timing, gather the last sampling\'s latents of all ranks (all_gather) and np.save them here (tests: '
+                         'N ranks must reproduce the 1-rank result of the same global batch bit for bit)')
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU rehearsal of the N-rank plumbing with an analytic stand-in model (tests); measures nothing')
     a = ap.parse_args()
@@ -265,6 +268,11 @@ def main():
         dist.all_gather(rates, torch.tensor([npg * a.steps / dt_own], dtype=torch.float64, device=dev))
         per_rank = [float(r.item()) for r in rates]
     assert torch.isfinite(out).all(), 'non-finite latents'
+    if a.dump_latents:
+        from fgdm_amd import dist as fd
+        allx = fd.gather_latents(out, rank, world) if use_dist else out
+        if rank == 0:
+            np.save(a.dump_latents, allx.float().cpu().numpy())
     if a.dry_run:
         if rank == 0:
             emit({'metric': '512x512 images/sec @ 50 DDIM steps, seg-ControlNet+CFG', 'dry_run': True, 'value': None,
@@ -349,12 +357,13 @@ def main():
             'workspace': engine.workspace_stats(),
         }
         log(f'{value:.3f} images/s; igemm {achieved:.0f} TFLOP/s')
-        if world == 1 and not a.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline()
-        emit(res)
-    if use_dist:
+    if use_dist:            # the other ranks are done: release them before rank 0 spends its 20-30 s on the CPU baseline
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()       # rank 0's host cores, after the timed region, at every N
+        emit(res)
 
 
 if __name__ == '__main__':

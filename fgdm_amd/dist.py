@@ -22,17 +22,25 @@ def shard(t, rank, world):
     return t[lo:hi]
 
 
+# Weights the engine transforms in fp32 BEFORE it rounds them to fp16 (fgdm_finalize_weights): a tensor shipped as fp16 would be
+# rounded twice there.  to_q: log2(e) d^-1/2 is folded in; the consumers of a folded LayerNorm (norm1 -> attn1.to_q|to_k|to_v,
+# norm2 -> attn2.to_q, norm3 -> ff.net.0.proj) are packed as fp16(gamma_k W_nk) with bias / u sums taken over the fp32 W; the text
+# encoder keeps its token / position embeddings in fp32 (fp32 residual stream), the first stage its 4x4 post_quant_conv.
+_FP32_SUFFIXES = ('attn1.to_q.weight', 'attn1.to_k.weight', 'attn1.to_v.weight', 'attn2.to_q.weight', 'ff.net.0.proj.weight',
+                  'token_embedding.weight', 'position_embedding.weight', 'post_quant_conv.weight')
+
+
 def _ships_as_fp16(key, shape):
-    """Tensors the engine stores as fp16 anyway may travel as fp16: every >= 2-D weight except the to_q projections (the
-    engine folds log2(e) d^-1/2 into them in fp32 BEFORE rounding).  1-D tensors (biases, norm affine) stay fp32 in the
-    engine and travel as fp32.  With this rule a rank fed from the broadcast computes bit-identical results to one that
-    loaded the fp32 state dict directly."""
-    return len(shape) >= 2 and not key.endswith('to_q.weight')
+    """Tensors the engine stores as fp16 UNCHANGED may travel as fp16: every >= 2-D weight except the ones listed in
+    _FP32_SUFFIXES.  1-D tensors (biases, norm affine) stay fp32 in the engine and travel as fp32.  With this rule a rank fed
+    from the broadcast holds bit-identical packed weights to one that loaded the fp32 state dict directly
+    (tests/test_gpu_dropin.py::test_broadcast_layout_is_bit_identical_to_fp32_load)."""
+    return len(shape) >= 2 and not key.endswith(_FP32_SUFFIXES)
 
 
 def broadcast_weights(shapes, make_tensor, rank, world, device, timing=None, force=False):
     """Rank 0 materialises every parameter (make_tensor(key, shape) -> float32 ndarray) into ONE flat byte buffer -- fp16
-    where the engine keeps fp16 (2.5 GB for SD-v1.5 + one ControlNet instead of 4.9 GB of fp32), fp32 otherwise -- a single
+    where the engine keeps the tensor as fp16 unchanged (3.2 GB for SD-v1.5 + one ControlNet instead of 4.9 GB of fp32), fp32 otherwise -- a single
     broadcast ships it (RCCL over xGMI on GPUs, gloo in the CPU tests) and every rank returns {key: view} plus the
     buffer.  With world == 1 nothing is communicated.  timing: optional dict, receives 'bcast_s' and 'bcast_bytes'."""
     import time
@@ -45,10 +53,21 @@ def broadcast_weights(shapes, make_tensor, rank, world, device, timing=None, for
         off += (nbytes + 15) & ~15            # 16-byte aligned views
     flat = torch.empty(off, dtype=torch.uint8, device=device)
     if rank == 0:
-        for k, s in shapes.items():
+        # the tensors are independent (one counter-based stream per key: fgdm_amd/synth.py; a checkpoint loader would read them
+        # from disk): materialise them on a few host threads -- the other ranks wait for this broadcast and nothing else
+        import concurrent.futures as cf
+        import os
+
+        def fill(k):
             o, nbytes, dt = layout[k]
-            src = torch.from_numpy(np.ascontiguousarray(make_tensor(k, s), dtype=np.float32).ravel()).to(dt)
+            src = torch.from_numpy(np.ascontiguousarray(make_tensor(k, shapes[k]), dtype=np.float32).ravel()).to(dt)
             flat[o:o + nbytes].view(dt).copy_(src)
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        with cf.ThreadPoolExecutor(max_workers=max(1, min(cores, 16))) as pool:
+            list(pool.map(fill, list(shapes)))
     if world > 1 or force:      # force: issue the collective even for one rank (rehearsal of the RCCL call)
         if flat.is_cuda:
             torch.cuda.synchronize()

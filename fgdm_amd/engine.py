@@ -99,6 +99,34 @@ def _ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+class ContextCachePolicy:
+    """Which conditioning tensor's to_k / to_v projections the engine holds (fgdm_set_context: a free, ~50 hipMallocs and a sync).
+    The samplers hand the SAME tensor object to every denoising step, so registering on a miss is right -- unless the caller
+    ALTERNATES two contexts (guess mode: the conditional and the unconditional call of every step,
+    controlnet/cldm/ddim_hacked.py:190-191; seg2image): then one of them stays registered and the other is passed along and
+    projected from the workspace on every call.  see(ctx) -> 'hit' | 'register' | 'bypass'; holding the object keeps its storage
+    from being recycled under the same address, torch bumps _version on in-place writes."""
+
+    def __init__(self, window=4):
+        import collections
+        self.obj, self.ver = None, -1
+        self.recent = collections.deque(maxlen=window)       # (id, version) of the last contexts seen
+        self.registrations = 0
+
+    def see(self, ctx):
+        key = (id(ctx), ctx._version)
+        if ctx is self.obj and ctx._version == self.ver:
+            verdict = 'hit'
+        elif key in self.recent and any(k != key for k in self.recent):
+            verdict = 'bypass'            # seen a moment ago with another context in between: an alternation, not a new prompt
+        else:
+            verdict = 'register'
+            self.obj, self.ver = ctx, ctx._version
+            self.registrations += 1
+        self.recent.append(key)
+        return verdict
+
+
 class Engine:
     """One engine per device: owns packed weights + activation workspace in HBM."""
 
@@ -122,7 +150,7 @@ class Engine:
         self.n_controlnets = n_controlnets
         self.use_adapter = bool(use_adapter)
         self._hint_keys = [None] * n_controlnets
-        self._ctx_obj, self._ctx_ver = None, -1     # context tensor whose K/V projections the engine holds
+        self._ctx_policy = ContextCachePolicy()      # context tensor whose K/V projections the engine holds
         self._conds_key, self._conds_keep = None, None
         self.cache_context = os.environ.get('FGDM_CONTEXT_CACHE', '1') != '0'
 
@@ -183,7 +211,7 @@ class Engine:
 
     def finalize(self):
         self._check(self.lib.fgdm_finalize_weights(self.h), 'fgdm_finalize_weights')
-        self._ctx_obj, self._ctx_ver = None, -1
+        self._ctx_policy = ContextCachePolicy()
         self._hint_keys = [None] * self.n_controlnets
         self._conds_key, self._conds_keep = None, None
 
@@ -234,18 +262,11 @@ class Engine:
         # holding the object keeps its storage from being recycled under the same address).
         ctx_arg = None
         if self.cache_context and ctx.is_cuda and ctx.dtype == torch.float32 and ctx.is_contiguous():
-            if ctx is self._ctx_obj and ctx._version == self._ctx_ver:
-                self._ctx_thrash = 0
-            else:
-                # callers that ALTERNATE two contexts (guess mode: the conditional and the unconditional call of every step,
-                # controlnet/cldm/ddim_hacked.py:190-191) would re-register (free + ~50 hipMallocs + a sync) on every call:
-                # after two misses in a row the context is simply passed along and projected from the workspace instead
-                self._ctx_thrash = getattr(self, '_ctx_thrash', 0) + 1
-                if self._ctx_thrash <= 1:
-                    self._check(self.lib.fgdm_set_context(self.h, _ptr(ctx), B, _stream()), 'fgdm_set_context')
-                    self._ctx_obj, self._ctx_ver = ctx, ctx._version
-                else:
-                    ctx_arg = ctx
+            verdict = self._ctx_policy.see(ctx)
+            if verdict == 'register':
+                self._check(self.lib.fgdm_set_context(self.h, _ptr(ctx), B, _stream()), 'fgdm_set_context')
+            elif verdict == 'bypass':
+                ctx_arg = ctx
         else:
             ctx_arg = ctx.to(self.device, torch.float32).contiguous()
         eps = torch.empty_like(x) if out is None else out
@@ -370,7 +391,7 @@ class Engine:
             sc_ptr = C.c_void_p(0)
         rc = self.lib.fgdm_sample_ddim(self.h, _ptr(x), _ptr(cond), _ptr(uncond), float(cfg_scale), S, ts, fa(alphas),
                                        fa(alphas_prev), fa(sqrt_one_minus_alphas), sc_ptr, B, H, W, flags, _stream())
-        self._ctx_obj, self._ctx_ver = None, -1      # the device-side loop registered its own context
+        self._ctx_policy = ContextCachePolicy()      # the device-side loop registered its own context
         self._check(rc, 'fgdm_sample_ddim')
         return x
 

@@ -20,6 +20,11 @@
                   running max stay fp32; probabilities are rounded to fp16 for the PV product, the normaliser is the
                   sum of those fp16 probabilities (head dims with a spare MFMA row: 40, 80) or of the fp32 ones (160);
                 * the stacked emb_layers output, the final conv's eps and all sampler state are fp32.
+  'w16'       fp16 WEIGHTS (``wt``, as 'engine' rounds them), every activation exact fp32 (``st`` is the identity, LayerNorms stay
+              separate): the smallest change any engine that hands fp16 weights to the MFMA makes to the reference's CPU path.
+              tests/test_oracle_autocast.py::test_fp16_weights_alone_cost_1e_3 holds its distance from 'fp32' on a whole
+              network as a number: the literal 1e-3 of the north star is out of reach before a single activation is rounded.
+              (the next line is about 'engine':)
               Against this mode the engine differs only by fp32 summation order: blocks agree to < 1e-3 (tests/test_gpu_blocks.py);
               whole networks do not -- fp16 storage amplifies ANY perturbation to the 1e-3 level (tests/test_oracle_autocast.py).
 """
@@ -40,7 +45,7 @@ def st(x):
 
 def wt(t, scale=None):
     """A weight as the engine's packed copy holds it (fp16, optionally pre-multiplied in fp32); cached."""
-    if MODE != 'engine':
+    if MODE not in ('engine', 'w16'):
         return t if scale is None else t * scale
     key = (t.data_ptr(), t.numel(), scale)
     hit = _wcache.get(key)
@@ -59,9 +64,9 @@ def like(y, x):
 
 @contextlib.contextmanager
 def mode(name):
-    """``with precision.mode('engine'):`` / ``'autocast'`` / ``'fp32'``."""
+    """``with precision.mode('engine'):`` / ``'autocast'`` / ``'fp32'`` / ``'w16'``."""
     global MODE
-    if name not in ('fp32', 'autocast', 'engine'):
+    if name not in ('fp32', 'autocast', 'engine', 'w16'):
         raise ValueError(name)
     prev = MODE
     MODE = name
@@ -74,5 +79,5 @@ def mode(name):
             yield None
     finally:
         MODE = prev
-        if name == 'engine':
+        if name in ('engine', 'w16'):
             _wcache.clear()

@@ -47,21 +47,31 @@ def report(name, err, tol):
 #     err(engine, reference fp32)  <=  max(1e-3, NET_K * floor)      with the floor MEASURED on the same inputs,
 # i.e. the engine is no farther from the CPU path than the reference's own GPU numerics are.
 NET_K = 1.1
+# ... capped absolutely (the floor comes from this repo's CPU emulation of CUDA autocast, oracle/autocast.py: an error there must
+# not be able to widen the gate): one network evaluation 4e-3; several chained evaluations, or an evaluation whose CFG combine
+# (scale 9) multiplies the difference of two evaluations, 1e-2 -- the callers that need the second say so (cap=CAP_CHAIN).
+CAP_EVAL, CAP_CHAIN = 4e-3, 1e-2
+# ... and the SAME result must sit within AC_K floors of the reference's autocast golden: two independent fp16 evaluations
+# decorrelate to sqrt(2) x floor (tests/test_oracle_autocast.py::test_fp16_storage_is_chaotic); measured over all 52 comparisons
+# of profiles/r02_parity_errors.txt: 0.9 ... 1.32.  1.5 is the regression guard: a kernel that loses a quarter more trips it.
+AC_K = 1.5
 
 
-def net_tol(floor):
-    return max(1e-3, NET_K * floor)
+def net_tol(floor, cap=CAP_EVAL):
+    return min(max(1e-3, NET_K * floor), cap)
 
 
-def check_net(name, got, ref32, ref_ac):
-    """got vs the fp32 reference, judged against the measured autocast floor; also reports got vs ref_autocast."""
+def check_net(name, got, ref32, ref_ac, cap=CAP_EVAL):
+    """got vs the fp32 reference, judged against the measured autocast floor (capped), AND got vs ref_autocast."""
     ref32 = torch.as_tensor(ref32, dtype=torch.float32)
     ref_ac = torch.as_tensor(np.asarray(ref_ac, dtype=np.float32) if not isinstance(ref_ac, torch.Tensor) else ref_ac.float())
     floor = relerr(ref_ac, ref32)
-    tol = net_tol(floor)
+    tol = net_tol(floor, cap)
     e32 = report(f'{name} vs reference fp32 [floor(ref_autocast vs ref_fp32) {floor:.3e}]', relerr(got, ref32), tol)
-    report(f'{name} vs reference autocast', relerr(got, ref_ac), 2 * floor)
+    tol_ac = max(1e-3, AC_K * floor)
+    eac = report(f'{name} vs reference autocast', relerr(got, ref_ac), tol_ac)
     assert e32 < tol, (name, e32, floor)
+    assert eac < tol_ac, (name, eac, floor)
     return e32, floor
 
 
@@ -76,9 +86,9 @@ def oracle_modes(fn):
     return out
 
 
-def check_net_vs_oracle(name, got, fn):
+def check_net_vs_oracle(name, got, fn, cap=CAP_EVAL):
     """For cases without reference goldens: the oracle supplies fp32, autocast-policy and engine-policy results."""
     o32, oac, oen = oracle_modes(fn)
-    e32, floor = check_net(name, got, o32, oac)
+    e32, floor = check_net(name, got, o32, oac, cap)
     report(f'{name} vs oracle[engine policy]', relerr(got, oen), 2 * floor)
     return e32, floor

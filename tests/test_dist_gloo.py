@@ -70,3 +70,15 @@ def test_shard_bounds_rejects_ragged():
     from fgdm_amd import dist as fd
     with pytest.raises(ValueError):
         fd.shard_bounds(10, 0, 4)
+
+
+def test_shipping_rule_keeps_fp32_for_tensors_the_packer_transforms():
+    """fp16 shipping must not add a rounding in front of a fold (LayerNorm gamma, attention scale)."""
+    from fgdm_amd import dist as fd
+    two_d = (320, 320)
+    for k in ('x.attn1.to_q.weight', 'x.attn1.to_k.weight', 'x.attn1.to_v.weight', 'x.attn2.to_q.weight', 'x.ff.net.0.proj.weight',
+              'c.embeddings.token_embedding.weight', 'c.embeddings.position_embedding.weight', 'first_stage_model.post_quant_conv.weight'):
+        assert not fd._ships_as_fp16(k, two_d), k
+    for k in ('x.attn2.to_k.weight', 'x.attn2.to_v.weight', 'x.attn1.to_out.0.weight', 'x.ff.net.2.weight', 'x.in_layers.2.weight', 'x.proj_in.weight'):
+        assert fd._ships_as_fp16(k, two_d), k
+    assert not fd._ships_as_fp16('x.in_layers.2.bias', (320,))

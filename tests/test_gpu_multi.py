@@ -1,0 +1,39 @@
+"""The N > 1 path on real GPUs (skipped on a one-GPU box): `python bench.py --gpus 2` -- one process per GPU, RCCL weight broadcast
+over xGMI, prompt shards, no collective in the loop -- must give the 1-rank latents of the same global batch bit for bit
+(the reference itself is single-device: scripts/txt2img_fgdm_inference.py:179-180)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(gpus, prompts, dump):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--steps', '1', '--warmup', '0', '--ddim-steps', '2',
+           '--prompts', str(prompts), '--no-cpu-baseline', '--no-first-stage', '--dump-latents', dump]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)      # fresh processes only
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs on one node')
+def test_two_ranks_over_rccl_reproduce_one_rank(tmp_path):
+    two = _bench(2, 2, str(tmp_path / 'two.npy'))
+    assert two['n_gpus'] == 2 and len(two['per_rank_images_per_s']) == 2 and all(r > 0 for r in two['per_rank_images_per_s'])
+    assert two['weights']['bcast_s'] > 0 and two['weights']['bcast_bytes'] > 2e9
+    assert two['scaling'] == 'weak' and two['value'] > 0
+    one = _bench(1, 4, str(tmp_path / 'one.npy'))
+    assert one['n_gpus'] == 1
+    a, b = np.load(tmp_path / 'two.npy'), np.load(tmp_path / 'one.npy')
+    assert a.shape == b.shape == (4, 4, 64, 64)
+    assert np.array_equal(a, b), float(np.abs(a - b).max())

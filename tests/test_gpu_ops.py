@@ -414,3 +414,32 @@ def test_layernorm_folded_into_consumer_gemm(lib, case):
         a, g = z32.chunk(2, dim=-1)
         z32 = a * F.gelu(g)
     assert relerr(y.float().cpu(), z32) < TOL
+
+
+@pytest.mark.parametrize('offset', [8.0, 32.0], ids=lambda o: f'row_mean_{int(o)}_std')
+def test_layernorm_fold_rows_with_large_mean(lib, offset):
+    """ADVICE r2: the folded LayerNorm takes its variance as E[x^2] - mean^2 from fp32 partial sums and forms acc - mean u in fp32;
+    both cancel when |mean| >> std.  Token rows shifted by `offset` standard deviations plus a few outlier channels (what real
+    checkpoints produce) must stay inside the per-kernel bar -- measured against LayerNorm -> Linear in fp64 ON THE ENGINE'S OWN
+    fp16 h (the fp16 storage of a row with a large mean loses the same bits in the reference's autocast path)."""
+    M, K1, Cc, N2 = 4096, 320, 320, 640
+    x = rnd((M, K1), 1).half()
+    w1, b1 = rnd((Cc, K1), 2, K1 ** -0.5), rnd((Cc,), 3, 0.1)
+    res = rnd((M, Cc), 4) + offset * (0.5 + rnd((M, 1), 9).abs())          # row means of 0.5 ... 1.5 x offset, unit spread
+    res[:, ::97] += 6.0 * rnd((M, Cc), 10)[:, ::97]                         # four outlier channels
+    res = res.half()
+    gamma, beta = 1.0 + 0.2 * rnd((Cc,), 5), 0.1 * rnd((Cc,), 6) + 0.05
+    w2, b2 = rnd((N2, Cc), 7, Cc ** -0.5), rnd((N2,), 8, 0.1)
+    h = torch.empty(M, Cc, dtype=torch.float16, device='cuda')
+    y = torch.empty(M, N2, dtype=torch.float16, device='cuda')
+    slots = C.c_int(0)
+    ws = [t.cuda() for t in (w1, b1, gamma, beta, w2, b2)]
+    rc = lib.fgdm_op_linear_ln_linear(_p(x.cuda()), _p(ws[0]), _p(ws[1]), _p(res.cuda()), _p(ws[2]), _p(ws[3]), _p(ws[4]), _p(ws[5]), M,
+                                      K1, Cc, N2, 0, _p(h), _p(y), C.byref(slots), _st())
+    assert rc == 0
+    hh = h.double().cpu()
+    wf = h16(w2 * gamma[None, :]).double()
+    z = F.linear(F.layer_norm(hh, (Cc,), None, None, 1e-5), wf, (w2.double() @ beta.double() + b2.double()))
+    err = relerr(y.double().cpu(), z)
+    print(f'LayerNorm fold, row mean ~{offset:g} x std: rel_err={err:.3e}')
+    assert err < TOL

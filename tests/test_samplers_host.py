@@ -241,3 +241,22 @@ def test_sampler_branches_vs_reference(stubs):
         return M()
     err = sampler_branches.run(make_model, 'cpu', STOL)
     print(err)
+
+
+def test_context_cache_policy_registers_once_under_alternation():
+    """guess mode alternates two contexts (ddim_hacked.py:190-191); the engine must not re-register (free + ~50
+    hipMallocs + sync) every third call.  One of the two stays registered, the other is passed along."""
+    from fgdm_amd.engine import ContextCachePolicy
+    a, b, c = torch.zeros(2, 77, 8), torch.zeros(2, 77, 8), torch.zeros(2, 77, 8)
+    pol = ContextCachePolicy()
+    seq = [pol.see(t) for t in (a, b) * 10]
+    assert pol.registrations == 2 and seq[:2] == ['register', 'register'] and set(seq[2:]) == {'hit', 'bypass'}
+    assert seq[2::2] == ['bypass'] * 9 and seq[3::2] == ['hit'] * 9
+    # the ordinary case: the same object every step, a new one per sample() call
+    pol = ContextCachePolicy()
+    assert [pol.see(a) for _ in range(5)] == ['register'] + ['hit'] * 4
+    assert [pol.see(c) for _ in range(3)] == ['register', 'hit', 'hit']
+    # an in-place write invalidates (torch bumps _version)
+    c.add_(1.0)
+    assert pol.see(c) == 'register' and pol.see(c) == 'hit'
+    assert pol.registrations == 3
