@@ -77,6 +77,7 @@ SIGNATURES = {
     'fgdm_op_linear_ln_linear': (_i, [_p] * 8 + [_i] * 5 + [_p, _p, C.POINTER(_i), _p]),
     'fgdm_bench_norm': (_i, [_i] * 7 + [C.POINTER(_f)]),
     'fgdm_bench_attention': (_i, [_i] * 6 + [C.POINTER(_f)]),
+    'fgdm_bench_ff': (_i, [_i] * 4 + [C.POINTER(_f)]),
     'fgdm_op_groupnorm': (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _f, _i, _p, _p]),
     'fgdm_op_layernorm': (_i, [_p, _i, _i, _p, _p, _f, _p, _p]),
     'fgdm_op_attention': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -247,6 +247,15 @@ struct fgdm_engine {
     // (FGDM_LN_FOLD=0 at fgdm_create: the A/B switch for tools/ab_bench.sh; numerics differ only in rounding points)
     bool ln_fold = true;
     hipStream_t s = nullptr;      // stream of the call in flight
+    // FGDM_TWIN_STREAMS=1: the ControlNets run on a second stream (own arena: an arena's block reuse relies on stream order) next
+    // to the UNet encoder + middle block, which they do not depend on (cldm.py:40,46: the UNet takes `control` only after its middle
+    // block); their zero-convs are applied on the main stream behind a join event
+    Arena arena2;
+    Arena* ar = &arena;           // arena of the stream being enqueued
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool twin_streams = false;
+    struct Deferred { const GemmW* w; Tensor src; int idx; float scale; };
     Prof prof;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -831,10 +840,10 @@ struct fgdm_engine {
     // ------------------------------------------------------------------------------------ runtime helpers
     Tensor talloc(int B, int H, int W, int C) {
         Tensor t; t.B = B; t.H = H; t.W = W; t.C = C;
-        t.p = (half_t*)arena.alloc(t.numel() * sizeof(half_t));
+        t.p = (half_t*)ar->alloc(t.numel() * sizeof(half_t));
         return t;
     }
-    void tfree(Tensor& t) { arena.release(t.p); t.p = nullptr; }
+    void tfree(Tensor& t) { ar->release(t.p); t.p = nullptr; }
 
     // LayerNorm partial sums of a token matrix (IgemmArgs::stats_out / ln_stats): [rows][slots][2] floats in the arena
     struct LnStats { float* p = nullptr; int slots = 0; };
@@ -878,7 +887,7 @@ struct fgdm_engine {
         if (prof.on) snprintf(tag, sizeof(tag), "igemm M%d N%d K%d mode%d act%d out%d", a.M, a.N, a.K, a.mode, a.act, a.out_kind);
         a.splitk = igemm_splitk_factor(a);
         if (a.splitk > 1) {
-            a.ws = (float*)arena.alloc((size_t)a.splitk * a.M * a.N * sizeof(float));
+            a.ws = (float*)ar->alloc((size_t)a.splitk * a.M * a.N * sizeof(float));
             if (!a.ws) return fail(FGDM_ERR_NOMEM, "workspace (split-K partials)");
         }
         if (e.ln) {
@@ -889,7 +898,7 @@ struct fgdm_engine {
         }
         if (e.stats) {     // partial sums of the output rows: from the GEMM's own epilogue when its kernel can, else one more pass
             e.stats->slots = igemm_stats_slots(a);
-            e.stats->p = (float*)arena.alloc((size_t)a.M * std::max(e.stats->slots, row_stats_slots(nout)) * 2 * sizeof(float));
+            e.stats->p = (float*)ar->alloc((size_t)a.M * std::max(e.stats->slots, row_stats_slots(nout)) * 2 * sizeof(float));
             if (!e.stats->p) return fail(FGDM_ERR_NOMEM, "workspace (LayerNorm statistics)");
             if (e.stats->slots) a.stats_out = e.stats->p;
         }
@@ -901,7 +910,7 @@ struct fgdm_engine {
         }
         int rc = igemm_launch(a, s);
         prof.end(s);
-        if (a.ws) arena.release(a.ws);
+        if (a.ws) ar->release(a.ws);
         if (rc == FGDM_OK && e.stats && e.stats->slots == 0) {
             if (a.out_kind != OUT_F16 || a.ld_out != nout) return fail(FGDM_ERR_ARG, "gemm: row statistics need a dense fp16 output");
             e.stats->slots = row_stats_slots(nout);
@@ -939,7 +948,7 @@ struct fgdm_engine {
     int gnorm(const NormW& n, const Tensor& x, const Tensor* x1, float eps, bool silu, Tensor* out) {
         const int C = x.C + (x1 ? x1->C : 0);
         *out = talloc(x.B, x.H, x.W, C);
-        float* ws = (float*)arena.alloc(groupnorm_ws_floats(x.B, x.H * x.W) * sizeof(float));
+        float* ws = (float*)ar->alloc(groupnorm_ws_floats(x.B, x.H * x.W) * sizeof(float));
         if (!out->p || !ws) return fail(FGDM_ERR_NOMEM, "workspace");
         char tag[56] = "";
         if (prof.on) snprintf(tag, sizeof(tag), "groupnorm B%d HW%d C%d", x.B, x.H * x.W, C);
@@ -947,7 +956,7 @@ struct fgdm_engine {
         const int rc = groupnorm_launch(x.p, x.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, x.B, x.H * x.W, n.g, n.b, eps,
                                         silu ? 1 : 0, out->p, ws, s);
         prof.end(s);
-        arena.release(ws);
+        ar->release(ws);
         return rc == FGDM_OK ? rc : fail(rc, "groupnorm launch failed");
     }
     int lnorm(const NormW& n, const Tensor& x, Tensor* out) {
@@ -1075,7 +1084,7 @@ struct fgdm_engine {
         { Epi e; if (ln_fold) e.ln = &s1; e.out = qk.p; e.ld_out = 2 * C; e.rps = T;
           e.out2 = vt.p; e.out_kind2 = OUT_F16_T; e.ld_out2 = Tp; e.split_n = 2 * C;
           CHK(linear(l.qkv1, a1, e, nullptr)); }
-        if (s1.p) arena.release(s1.p);
+        if (s1.p) ar->release(s1.p);
         if (nrm.p) tfree(nrm);
         a = talloc(B, x.H, x.W, C);
         if (!a.p) return fail(FGDM_ERR_NOMEM, "workspace");
@@ -1095,16 +1104,16 @@ struct fgdm_engine {
         }
         if (dup && ln_fold) {
             const size_t sb = (size_t)(B / 2) * T * s2.slots * 2 * sizeof(float);
-            float* s2f = (float*)arena.alloc(2 * sb);
+            float* s2f = (float*)ar->alloc(2 * sb);
             if (!s2f) return fail(FGDM_ERR_NOMEM, "workspace");
             HIP_TRY(hipMemcpyAsync(s2f, s2.p, sb, hipMemcpyDeviceToDevice, s));
             HIP_TRY(hipMemcpyAsync((char*)s2f + sb, s2.p, sb, hipMemcpyDeviceToDevice, s));
-            arena.release(s2.p); s2.p = s2f;
+            ar->release(s2.p); s2.p = s2f;
         }
         // --- attn2 (cross, 77-token context), norm2 folded into to_q
         if (!ln_fold) CHK(lnorm(l.ln2, h2, &nrm));
         { Epi e; if (ln_fold) e.ln = &s2; CHK(linear(l.q2, ln_fold ? h2 : nrm, e, &q2)); }
-        if (s2.p) arena.release(s2.p);
+        if (s2.p) ar->release(s2.p);
         if (nrm.p) tfree(nrm);
         int Tk, Tkp;
         const bool cached = (ctx16.p == nullptr);
@@ -1131,7 +1140,7 @@ struct fgdm_engine {
         // --- GEGLU feed-forward, norm3 folded into the projection
         if (!ln_fold) CHK(lnorm(l.ln3, h, &nrm));
         { Epi e; if (ln_fold) e.ln = &s3; e.act = ACT_GEGLU; CHK(linear(l.ffp, ln_fold ? h : nrm, e, &f)); }
-        if (s3.p) arena.release(s3.p);
+        if (s3.p) ar->release(s3.p);
         if (nrm.p) tfree(nrm);
         { Epi e; e.resid = h.p; e.ld_res = C; CHK(linear(l.ffo, f, e, &h2)); }
         tfree(f); tfree(h);
@@ -1206,7 +1215,7 @@ struct fgdm_engine {
         if (timestep_embed(t, tf, te.p, B, mc, B, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "timestep_embed");
         { Epi e; e.act = ACT_SILU; e.rps = 1; CHK(linear(n.time0, te, e, &e1)); }
         { Epi e; e.act = ACT_SILU; e.rps = 1; CHK(linear(n.time2, e1, e, &e2)); }   // = SiLU(emb): the only use of emb
-        *emb_all = (float*)arena.alloc((size_t)B * n.emb_total * sizeof(float));
+        *emb_all = (float*)ar->alloc((size_t)B * n.emb_total * sizeof(float));
         if (!*emb_all) return fail(FGDM_ERR_NOMEM, "workspace");
         { Epi e; e.out_kind = OUT_F32; e.out = *emb_all; e.ld_out = n.emb_total; e.rps = 1; CHK(linear(n.emb_all, e2, e, nullptr)); }
         tfree(te); tfree(e1); tfree(e2);
@@ -1369,7 +1378,7 @@ struct fgdm_engine {
         if (needs_emb) {   // emb_layers = SiLU -> Linear on the given `emb` (openaimodel.py:238-244), all ResBlocks in one GEMM
             const int temb = 4 * cfg.model_channels;
             Tensor e2 = talloc(1, 1, B, temb);
-            emb_all = (float*)arena.alloc((size_t)B * net->emb_total * sizeof(float));
+            emb_all = (float*)ar->alloc((size_t)B * net->emb_total * sizeof(float));
             if (!e2.p || !emb_all) return fail(FGDM_ERR_NOMEM, "workspace");
             if (silu_f32_to_f16(emb, e2.p, e2.numel(), s) != FGDM_OK) return fail(FGDM_ERR_HIP, "silu kernel");
             { Epi e; e.out_kind = OUT_F32; e.out = emb_all; e.ld_out = net->emb_total; e.rps = 1; CHK(linear(net->emb_all, e2, e, nullptr)); }
@@ -1382,7 +1391,7 @@ struct fgdm_engine {
         tfree(y); tfree(xin);
         if (xsk.p) tfree(xsk);
         if (ctx16.p) tfree(ctx16);
-        if (emb_all) arena.release(emb_all);
+        if (emb_all) ar->release(emb_all);
         if (out_numel) *out_numel = off;
         return FGDM_OK;
     }
@@ -1399,8 +1408,25 @@ struct fgdm_engine {
     // ControlNet.forward (cldm.py:792-813).  fused = true: every zero-conv output is scaled and ADDED in place into
     // the UNet's skip tensor hs[i] / h_mid (cldm.py:40,46 + :846), so control residuals never hit HBM separately.
     // fused = false: raw residuals are written as fp32 NCHW into out32 (test entry).
+    // dst <- dst + scale (W src + b), in place (cldm.py:40,46,846 fused into the zero-conv's epilogue)
+    int zero_conv_into(const GemmW& zw, const Tensor& src, Tensor& dst, float scale) {
+        Epi e;
+        e.scale = scale;
+        if (src.B * 2 == dst.B) {      // shared half: the same residual goes into both halves of the UNet's skip tensor
+            for (int half = 0; half < 2; ++half) {
+                half_t* d = dst.p + (size_t)half * (dst.numel() / 2);
+                e.resid = d; e.ld_res = dst.C; e.out = d; e.ld_out = dst.C;
+                CHK(linear(zw, src, e, nullptr));
+            }
+            return FGDM_OK;
+        }
+        e.resid = dst.p; e.ld_res = dst.C; e.out = dst.p; e.ld_out = dst.C;
+        return linear(zw, src, e, nullptr);
+    }
+
     int controlnet_fwd(Net& n, const Tensor& x4, const int64_t* t, const float* tf, const Tensor& ctx16, const float* scales,
-                       std::vector<Tensor>* hs, Tensor* h_mid, bool only_mid, float* out32, int64_t out_cap, bool pairs = false) {
+                       std::vector<Tensor>* hs, Tensor* h_mid, bool only_mid, float* out32, int64_t out_cap, bool pairs = false,
+                       std::vector<Deferred>* defer = nullptr) {
         const int B = x4.B;
         // CFG pairs: rows b and b + B/2 carry the same x, t and hint -> input blocks 0 and 1 (up to the first
         // cross-attention) are evaluated once on B/2 rows
@@ -1422,19 +1448,10 @@ struct fgdm_engine {
                 off += cnt;
                 return linear(zw, src, e, nullptr);
             }
-            Tensor& dst = idx < 0 ? *h_mid : (*hs)[idx];
             if (idx >= 0 && only_mid) return FGDM_OK;
             e.scale = scales ? scales[idx < 0 ? (int)n.input.size() : idx] : 1.f;
-            if (src.B * 2 == dst.B) {      // shared half: the same residual goes into both halves of the UNet's skip tensor
-                for (int half = 0; half < 2; ++half) {
-                    half_t* d = dst.p + (size_t)half * (dst.numel() / 2);
-                    e.resid = d; e.ld_res = dst.C; e.out = d; e.ld_out = dst.C;
-                    CHK(linear(zw, src, e, nullptr));
-                }
-                return FGDM_OK;
-            }
-            e.resid = dst.p; e.ld_res = dst.C; e.out = dst.p; e.ld_out = dst.C;
-            return linear(zw, src, e, nullptr);
+            if (defer) { defer->push_back({&zw, src, idx, e.scale}); return FGDM_OK; }     // applied by the caller on the main stream
+            return zero_conv_into(zw, src, idx < 0 ? *h_mid : (*hs)[idx], e.scale);
         };
         for (size_t i = 0; i < n.input.size(); ++i) {
             Tensor nxt;
@@ -1457,18 +1474,18 @@ struct fgdm_engine {
                     }
                 }
             } else if (shared && i == 1) {
-                CHK(block_fwd_shared(n.input[1], h, true, ec, ctx16, &nxt));    // B/2 rows in, B rows out
+                CHK(block_fwd_shared(n.input[1], h, !defer, ec, ctx16, &nxt));    // B/2 rows in, B rows out
             } else {
-                CHK(block_fwd(n.input[i], h, true, nullptr, ec, ctx16, nullptr, &nxt));
+                CHK(block_fwd(n.input[i], h, !defer, nullptr, ec, ctx16, nullptr, &nxt));
             }
             h = nxt;
             CHK(zero_conv(n.zero_convs[i], h, (int)i));
         }
         Tensor m;
-        CHK(block_fwd(n.middle, h, true, nullptr, ec, ctx16, nullptr, &m));
+        CHK(block_fwd(n.middle, h, !defer, nullptr, ec, ctx16, nullptr, &m));
         CHK(zero_conv(n.mid_out, m, -1));
-        tfree(m);
-        arena.release(emb);
+        if (!defer) tfree(m);
+        ar->release(emb);
         return FGDM_OK;
     }
 
@@ -1508,6 +1525,22 @@ struct fgdm_engine {
                 CHK(n.time_adapter ? time_adapter_fwd(n, x4s, ec, fa) : adapter_fwd(n, x4s, fa));
             }
         }
+        // ---- twin streams: the ControlNets start now, next to the UNet encoder
+        const bool with_cn = !cns.empty() && !(flags & FGDM_FLAG_NO_CONTROL);
+        const bool twin = twin_streams && with_cn && s2 && !(flags & FGDM_FLAG_ONLY_MID_CONTROL);
+        std::vector<Deferred> deferred;
+        if (twin) {
+            if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, ev_fork, 0) != hipSuccess) return fail(FGDM_ERR_HIP, "stream fork");
+            hipStream_t main_s = s;
+            s = s2; ar = &arena2;
+            int rc = FGDM_OK;
+            for (size_t c = 0; c < cns.size() && rc == FGDM_OK; ++c)
+                rc = controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, nullptr, nullptr, false, nullptr, 0, pairs,
+                                    &deferred);
+            s = main_s; ar = &arena;
+            if (rc != FGDM_OK) return rc;
+            if (hipEventRecord(ev_join, s2) != hipSuccess) return fail(FGDM_ERR_HIP, "stream join");
+        }
         // ---- encoder (openaimodel.py:849-858); the adapter feature is added BEFORE the skip is recorded
         std::vector<Tensor> hs;
         Tensor h;
@@ -1544,7 +1577,13 @@ struct fgdm_engine {
         Tensor hm;
         CHK(block_fwd(n.middle, h, false, nullptr, ec, ctx16, nullptr, &hm));
         // ---- ControlNets: residuals accumulate in place into hs / hm (cldm.py:40,46,846)
-        if (!cns.empty() && !(flags & FGDM_FLAG_NO_CONTROL)) {
+        if (twin) {
+            if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return fail(FGDM_ERR_HIP, "stream join");
+            for (const Deferred& d : deferred) CHK(zero_conv_into(*d.w, d.src, d.idx < 0 ? hm : hs[d.idx], d.scale));
+            // the ControlNets' block outputs go back to their own arena: its next user is the next call's second stream, which
+            // waits for that call's fork event, recorded behind these zero-convs
+            for (Deferred& d : deferred) { arena2.release(d.src.p); d.src.p = nullptr; }
+        } else if (with_cn) {
             for (size_t c = 0; c < cns.size(); ++c)
                 CHK(controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, &hs, &hm,
                                    (flags & FGDM_FLAG_ONLY_MID_CONTROL) != 0, nullptr, 0, pairs));
@@ -1567,7 +1606,7 @@ struct fgdm_engine {
         tfree(g);
         tfree(x4);
         if (ctx16.p) tfree(ctx16);
-        arena.release(emb);
+        ar->release(emb);
         return FGDM_OK;
     }
 
@@ -1581,8 +1620,8 @@ struct fgdm_engine {
         // the hidden states are an fp32 residual stream, as under the reference's autocast: fp32 embeddings, every branch
         // (attention / MLP output, a fp16 GEMM result) is promoted when added to it, LayerNorm reads fp32
         Tensor n, qkv, a, f;
-        float* h = (float*)arena.alloc((size_t)rows * W * sizeof(float));
-        float* h2 = (float*)arena.alloc((size_t)rows * W * sizeof(float));
+        float* h = (float*)ar->alloc((size_t)rows * W * sizeof(float));
+        float* h2 = (float*)ar->alloc((size_t)rows * W * sizeof(float));
         if (!h || !h2) return fail(FGDM_ERR_NOMEM, "workspace");
         if (embed_tokens(ids, clip.tok, clip.pos, h, rows, T, W, cfg.clip_vocab, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "embedding kernel");
         auto ln32 = [&](const NormW& nw, const float* src, Tensor* dst) -> int {
@@ -1614,7 +1653,7 @@ struct fgdm_engine {
         }
         // final_layer_norm: fp32 in, fp32 out -- straight into the caller's buffer
         if (layernorm32_launch(h, rows, W, clip.final_ln.g, clip.final_ln.b, 1e-5f, nullptr, out, s) != FGDM_OK) return fail(FGDM_ERR_HIP, "layernorm");
-        arena.release(h); arena.release(h2);
+        ar->release(h); ar->release(h2);
         return FGDM_OK;
     }
 
@@ -1649,7 +1688,7 @@ struct fgdm_engine {
         vt = talloc(B, 1, C, T);
         a = talloc(B, x.H, x.W, C);
         P = talloc(1, 1, T, T);
-        float* S = (float*)arena.alloc((size_t)T * T * sizeof(float));
+        float* S = (float*)ar->alloc((size_t)T * T * sizeof(float));
         if (!k.p || !vt.p || !a.p || !P.p || !S) return fail(FGDM_ERR_NOMEM, "workspace");
         HIP_TRY(hipMemsetAsync(k.p + (size_t)B * T * C, 0, (size_t)128 * C * sizeof(half_t), s));
         { Epi e; e.out = k.p; e.ld_out = C; e.rps = T; CHK(linear(v.ak, g, e, nullptr)); }
@@ -1665,7 +1704,7 @@ struct fgdm_engine {
             { Epi e; e.out = a.p + (size_t)b * T * C; e.ld_out = C; e.rps = T;
               CHK(gemm(wv, IG_LINEAR, P, nullptr, 1, T, e, nullptr)); }
         }
-        arena.release(S);
+        ar->release(S);
         tfree(P); tfree(q); tfree(k); tfree(vt);
         { Epi e; e.resid = x.p; e.ld_res = C; CHK(linear(v.ao, a, e, out)); }
         tfree(a);
@@ -1775,9 +1814,15 @@ static int make_desc(const fgdm_config* cfg, fgdm_engine** out) {
 // One C-ABI call that uses the activation workspace: on a non-OK return everything it still holds goes back to the arena
 template <typename F> static int scoped_call(fgdm_engine* e, void* stream, F f) {
     e->s = as_stream(stream);
+    e->ar = &e->arena;
     e->arena.begin_scope();
+    e->arena2.begin_scope();
     const int rc = f();
+    e->s = as_stream(stream);
+    e->ar = &e->arena;
+    if (rc != FGDM_OK && e->s2) (void)hipStreamSynchronize(e->s2);      // nothing of the second stream may outlive its blocks
     e->arena.end_scope(rc != FGDM_OK);
+    e->arena2.end_scope(rc != FGDM_OK);
     return rc;
 }
 
@@ -1798,6 +1843,17 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
         delete e;
         return rc;
     }
+    if (const char* v = getenv("FGDM_TWIN_STREAMS")) e->twin_streams = atoi(v) != 0;
+    if (e->twin_streams && !e->cns.empty()) {
+        if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+            g_create_err = "second stream could not be created";
+            delete e;
+            return FGDM_ERR_HIP;
+        }
+        if (e->cfg.workspace_bytes > 0) e->arena2.slab_bytes = (size_t)e->cfg.workspace_bytes;
+    }
     *out = e;
     return FGDM_OK;
 }
@@ -1810,6 +1866,9 @@ void fgdm_destroy(fgdm_engine* e) {
     for (auto& n : e->cns) if (n.guided.p) (void)hipFree(n.guided.p);
     e->drop_context();
     e->drop_adapter_conds();
+    if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     delete e;
 }
 
@@ -2263,6 +2322,61 @@ int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, i
     for (int i = 0; i < 3 && rc == FGDM_OK; ++i) rc = igemm_launch(a, nullptr);
     HIP_TRY(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters && rc == FGDM_OK; ++i) rc = igemm_launch(a, nullptr);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// Feed-forward pair of a transformer block (GEGLU projection C -> 8C, then 4C -> C with the residual) on M random token rows,
+// evaluated in row chunks of `chunk` rows that reuse ONE intermediate buffer: does the 4C intermediate of a chunk stay on chip
+// (L2 / Infinity Cache) between its producer and its consumer?  chunk = M: the two launches the engine makes today.
+int fgdm_bench_ff(int M, int Cw, int chunk, int iters, float* avg_ms) {
+    if (!avg_ms || iters <= 0 || M <= 0 || chunk <= 0 || (Cw % 320) || (M % chunk)) return FGDM_ERR_ARG;
+    const int N1 = 8 * Cw, K2 = 4 * Cw;
+    unsigned st = 4321u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 9) & 0xffff) / 32768.0f - 1.0f; };
+    std::vector<half_t> hx((size_t)M * Cw), hw1(igemm_npad(N1) * (size_t)Cw), hw2(igemm_npad(Cw) * (size_t)K2);
+    std::vector<float> hb1(igemm_npad(N1)), hb2(igemm_npad(Cw));
+    for (auto& v : hx) v = (half_t)rnd();
+    for (auto& v : hw1) v = (half_t)(rnd() / sqrtf((float)Cw));
+    for (auto& v : hw2) v = (half_t)(rnd() / sqrtf((float)K2));
+    for (auto& v : hb1) v = rnd() * 0.1f;
+    for (auto& v : hb2) v = rnd() * 0.1f;
+    TmpDev tmp;
+    half_t *h = nullptr, *out = nullptr;
+    if (hipMalloc(&h, (size_t)chunk * K2 * sizeof(half_t)) != hipSuccess) return FGDM_ERR_NOMEM;
+    tmp.ptrs.push_back(h);
+    if (hipMalloc(&out, (size_t)M * Cw * sizeof(half_t)) != hipSuccess) return FGDM_ERR_NOMEM;
+    tmp.ptrs.push_back(out);
+    const half_t* x = tmp.up(hx);
+    IgemmArgs g{}, f{};
+    g.Wt = tmp.up(hw1); g.bias = tmp.up(hb1); g.zero = g_zero_page();
+    f.Wt = tmp.up(hw2); f.bias = tmp.up(hb2); f.zero = g.zero;
+    if (!x || !g.Wt || !g.bias || !f.Wt || !f.bias || !g.zero) return FGDM_ERR_NOMEM;
+    g.C0 = Cw; g.B = 1; g.H = 1; g.W = chunk; g.Ho = 1; g.Wo = chunk; g.M = chunk; g.N = N1; g.K = Cw; g.mode = IG_LINEAR;
+    g.act = ACT_GEGLU; g.out_kind = OUT_F16; g.out = h; g.ld_out = K2; g.rows_per_sample = chunk; g.scale = 1.f;
+    f.A0 = h; f.C0 = K2; f.B = 1; f.H = 1; f.W = chunk; f.Ho = 1; f.Wo = chunk; f.M = chunk; f.N = Cw; f.K = K2; f.mode = IG_LINEAR;
+    f.act = ACT_NONE; f.out_kind = OUT_F16; f.ld_out = Cw; f.ld_res = Cw; f.rows_per_sample = chunk; f.scale = 1.f;
+    auto pass = [&]() {
+        int rc = FGDM_OK;
+        for (int r0 = 0; r0 < M && rc == FGDM_OK; r0 += chunk) {
+            g.A0 = x + (size_t)r0 * Cw;
+            rc = igemm_launch(g, nullptr);
+            f.resid = x + (size_t)r0 * Cw; f.out = out + (size_t)r0 * Cw;
+            if (rc == FGDM_OK) rc = igemm_launch(f, nullptr);
+        }
+        return rc;
+    };
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = FGDM_OK;
+    for (int i = 0; i < 2 && rc == FGDM_OK; ++i) rc = pass();
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && rc == FGDM_OK; ++i) rc = pass();
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;

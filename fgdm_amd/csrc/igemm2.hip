@@ -729,6 +729,8 @@ int launch2(const IgemmArgs& a, hipStream_t s) {
                                                         : FGDM_ERR_ARG;
     }
     if (a.debug) return FGDM_ERR_ARG;
+    // split-K tiles leave as raw fp32 partial sums (no register stage at all): either K loop fits
+    if constexpr (SPLIT) return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 0, PIPE, false>(a, s);
     if constexpr (FAST && !SPLIT) {
         switch (fast_on ? epilogue_path<BM, GEGLU, LN>(a) : 0) {
             case 1: return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 1, PIPE, false>(a, s);
@@ -823,6 +825,9 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if (a.act == ACT_GEGLU && bn != 256) return FGDM_ERR_ARG;
     if (a.splitk > 1) {
         if (tile != 2 || a.ln_stats) return FGDM_ERR_ARG;
+        if (pipe)
+            return a.mode == IG_LINEAR ? launch2<128, 320, 4, 2, 4, false, false, true, 16, false, false, 1>(a, s)
+                                       : launch2<128, 320, 4, 2, 4, true, false, true, 16, false, false, 1>(a, s);
         return a.mode == IG_LINEAR ? launch2<128, 320, 4, 2, 4, false, false, true, 16, false, false, 0>(a, s)
                                    : launch2<128, 320, 4, 2, 4, true, false, true, 16, false, false, 0>(a, s);
     }

@@ -208,6 +208,9 @@ int fgdm_debug_force_igemm_cfg(int cfg);
 int fgdm_bench_igemm(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample, int act,
                      int use_resid, int cfg, int iters, float* avg_ms);
 /* ... one attention shape (softmax(QK^T d^-1/2) V over B x heads, T queries, Tk keys) ... */
+/* tools/bench_ff.py: GEGLU projection + output projection of a feed-forward block (ldm/modules/attention.py:37-64) in row
+ * chunks sharing one intermediate buffer; average device milliseconds for all M rows. */
+int fgdm_bench_ff(int M, int C, int chunk_rows, int iters, float* avg_ms);
 int fgdm_bench_attention(int B, int heads, int T, int Tk, int d, int iters, float* avg_ms);
 /* ... and one GroupNorm32(+SiLU) (kind 0, optional virtual concat C1) or LayerNorm (kind 1) shape. */
 int fgdm_bench_norm(int kind, int B, int HW, int C0, int C1, int silu, int iters, float* avg_ms);
