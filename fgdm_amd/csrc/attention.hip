@@ -347,20 +347,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
 // read in slots 2j+2 (A) and 2j+3 (B), each wave writes its share of it in its own X phase -- A in X(j) (slot 2j+1), B in
 // X(j-1) (slot 2j) -- which is after the last read of p(j-2) (slot 2j-1) and before the first read of p(j).  Every wave
 // executes the same number of barriers (B one extra at the start, A one extra at the end).
-// Measured and rejected: s_setprio 1 / 2 around the matrix slot (d = 40: 649 -> 608 TF/s, d = 80: 581 -> 592); 64 queries per
-// wave (two 32-query blocks share every K / V^T fragment read and every barrier; 194 VGPRs, one workgroup per CU): 651 -> 657 TF/s
-// at B = 32, 633 -> 627 at B = 16 -- LDS traffic and barrier count are not what holds this kernel.
-// Compiler scheduling strategies for this file (-mllvm -amdgpu-sched-strategy=max-ilp / iterative-ilp): 641 -> 415 / 645 TF/s.
-// Also built (round 2): a software-pipelined kernel in which ONE wave overlaps, per tile k, exp2 / pack of S(k) with the MFMAs
-// of P V (k-1) and Q K^T (k+1) (tools/experiments/attention_sp_variant.hip.txt keeps the last version).  What it took, in order:
-//   sched_group_barrier hints only, rare-rescale path with its own copy of the region        288 registers (AGPR copies)  415 TF/s
-//   O rescaled AFTER the region (P(k-1) joins O first), so one region serves both paths        228 VGPRs                    563
-//   ... the hints did not survive: v_exp hoisted out of the block.  Every MFMA followed by its 2-3 v_exp_f32 as VOLATILE ASM
-//   and a sched_barrier ("M ee M ee ... M eee M eee" in the ISA)                                                            586
-//   eight waves per workgroup (one K / V^T chunk per thread and tile)                                                       615
-//   global loads at the start of an iteration, their LDS stores at its END (the wait no longer sits in front of the MFMAs)  639
-// i.e. level with the ping-pong kernel (640), not ahead; without the K / V^T staging the same loop runs at 710-765.  Prefetch
-// distance two with two register sets changed nothing: hipcc's wait-count pass drains vmcnt to 0 across the loop back-edge.
+// (measured and rejected around this kernel, and the software-pipelined variants of rounds 2 and 3: DESIGN.md section 4.2 / 4.3)
 template <int D>
 __global__ __launch_bounds__(512) void attn_pp_kernel(const half_t* __restrict__ Q, int ldq,
                                                       const half_t* __restrict__ K, int ldk,
