@@ -155,6 +155,10 @@ def main():
                          'evaluation, so every layer shape is sampled uniformly); 1 = every launch')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend: nccl (= RCCL over xGMI, the product) or gloo (CPU rehearsal with --dry-run)')
+    ap.add_argument('--twin-streams', action='store_true',
+                    help='FGDM_TWIN_STREAMS=1: the ControlNets run on a second HIP stream next to the UNet encoder (DESIGN.md section 4.3). '
+                         'Off by default: launches of the two streams overlap, so per-launch durations (the roofline object, rocprof '
+                         'kernel statistics) stop being exclusive device time; the JSON line says "twin_streams": true')
     ap.add_argument('--dump-latents', default=None,
                     help='after timing, gather the last sampling\'s latents of all ranks (all_gather) and np.save them here (tests: '
                          'N ranks must reproduce the 1-rank result of the same global batch bit for bit)')
@@ -162,6 +166,8 @@ def main():
                     help='CPU rehearsal of the N-rank plumbing with an analytic stand-in model (tests); measures nothing')
     a = ap.parse_args()
 
+    if a.twin_streams:
+        os.environ['FGDM_TWIN_STREAMS'] = '1'          # read by fgdm_create; inherited by the ranks of --gpus N
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))       # nothing has touched the GPU yet
     # stdout carries exactly ONE line, the JSON: native libraries write there too (RCCL prints a version banner on the first
@@ -349,6 +355,7 @@ def main():
                 'note': 'AutoencoderKL.decode of the sampled latents in the same engine, outside the timed region; '
                         '1.27 TFLOP/image'},
             'per_rank_images_per_s': per_rank,
+            'twin_streams': os.environ.get('FGDM_TWIN_STREAMS') == '1',
             'weights': {'params': n_params, 'load_s': round(load_s, 2), 'bcast_s': wt.get('bcast_s'),
                         'bcast_bytes': wt.get('bcast_bytes'),
                         'note': 'one broadcast of a flat buffer from rank 0 (RCCL over xGMI): fp16 for the tensors the engine '

@@ -67,8 +67,9 @@ struct IgemmArgs {
     int force_cfg;         // 0 = pick automatically; k > 0 = tile configuration k-1 (tuning / benchmarks)
     int splitk;            // > 1: K is split over `splitk` workgroups per tile; fp32 partial tiles go to `ws`
     float* ws;             //      [splitk][M][N] and igemm_splitk_reduce applies the epilogue (deterministic order)
-    int debug;             // ablation switches for tools/bench_igemm.py only: 1 = skip global->LDS loads in the K loop,
-                           // 2 = skip the MFMAs, 4 = skip the epilogue stores (results are then meaningless)
+    int debug;             // ablation switches, honoured by the ABL instantiations tools/bench_igemm.py asks for and rejected everywhere
+                           // else: 1 = no global->LDS loads in the K loop, 4 = no epilogue, 8 = every load from the zero page,
+                           // 16 = no tap / channel walk (pipelined loop; results are then meaningless)
     // ---- LayerNorm folded into a LINEAR GEMM (attention.py:234-240: attn(norm(x)), ff(norm(x))).  A is the RAW row x; the
     // packed weights are W'[n][k] = fp16(gamma[k] W[n][k]), `bias` holds sum_k beta[k] W[n][k] + b[n], `ln_u` holds
     // sum_k W'[n][k]; with (mean, rstd) of row m from the producer's partial sums the epilogue evaluates

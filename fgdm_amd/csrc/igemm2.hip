@@ -403,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
         // per-slot byte offsets and tap-validity masks are precomputed, a stage's displacement is ONE scalar, the tap / channel
         // walk is branch-free, the weight pieces take the SGPR-base form, M0 is not saved, and the steps that refill (all but
         // the last STAGES - 1) are their own instantiation of the step, so nothing in them is conditional.
+        const StageSc sc_abl = stage_scalars(0, 4, 0);
         auto step = [&](auto RF, int kt, h8 (&cur)[MI], h8 (&nxt)[MI]) {
             constexpr bool REFILL = decltype(RF)::value;
             // my pieces of stage kt + 1 landed (kt + 2 may fly; it exists in every refilling step)
@@ -412,7 +413,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
             // lgkmcnt(0) in front of the first MFMA, i.e. behind the reads group 0 has just issued)
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
-            const StageSc sc = stage_scalars(kt + STAGES - 1, tap, cc);
+            StageSc sc = stage_scalars(kt + STAGES - 1, tap, cc);
+            if constexpr (ABL) {    // ablation 16: what the tap / channel walk and its scalar arithmetic cost (addresses then repeat)
+                if (a.debug & 16) { sc = sc_abl; sc.lbase = __builtin_amdgcn_readfirstlane(lds_addr(smem) + ((kt + STAGES - 1) & 3) * STAGE_BYTES); }
+            }
             bool refill = REFILL;
             if constexpr (ABL) refill = refill && !(a.debug & 1);
 #pragma unroll
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j % RW], cur[i], acc[j][i], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (REFILL) advance_bf();
+            if constexpr (REFILL) { if (!(ABL && (a.debug & 16))) advance_bf(); }
         };
         const int nr = max(nk - (STAGES - 1), 0);        // steps that refill
         int kt = 0;
