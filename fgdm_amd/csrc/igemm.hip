@@ -328,6 +328,7 @@ static int pick_force(const IgemmArgs& a) {
         if (force >= 4) force = 0;
         if (force == 0) return 0;
     }
+    static const bool small_tiles = !(getenv("FGDM_IGEMM_SMALL_TILES") && atoi(getenv("FGDM_IGEMM_SMALL_TILES")) == 0);        // A/B knob
     static const bool other_widths = !(getenv("FGDM_IGEMM_OTHER_WIDTHS") && atoi(getenv("FGDM_IGEMM_OTHER_WIDTHS")) == 0);   // A/B knob
     if (force == 0) {
         const bool geglu = a.act == ACT_GEGLU;
@@ -336,6 +337,8 @@ static int pick_force(const IgemmArgs& a) {
             const long b128 = (long)((a.M + 127) / 128) * (a.N / 320);
             if (b256 >= 192) force = 4;
             else if (b128 >= 96) force = 6;
+            else if (a.mode == IG_LINEAR && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && small_tiles &&
+                     (long)((a.M + 63) / 64) * (a.N / 160) >= 128) force = 11;     // 64x160 tiles: the 8x8 level's linears
         } else if (geglu && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= 128) {
             force = 5;
         } else if (!geglu && !a.ln_stats && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && other_widths) {

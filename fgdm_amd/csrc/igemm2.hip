@@ -744,27 +744,27 @@ int launch2(const IgemmArgs& a, hipStream_t s) {
     }
     return launch2p<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, 0, 0, false>(a, s);
 }
-template <int BM, int BN, bool GEGLU, int MS, int PIPE>
+template <int BM, int BN, bool GEGLU, int MS, int PIPE, int WM, int WN>
 int launch2m(const IgemmArgs& a, hipStream_t s) {
-    return a.mode == IG_LINEAR ? launch2<BM, BN, 4, 2, 4, false, GEGLU, false, MS, false, MS == 16, PIPE>(a, s)
-                               : launch2<BM, BN, 4, 2, 4, true, GEGLU, false, MS, false, MS == 16, PIPE>(a, s);
+    return a.mode == IG_LINEAR ? launch2<BM, BN, WM, WN, 4, false, GEGLU, false, MS, false, MS == 16, PIPE>(a, s)
+                               : launch2<BM, BN, WM, WN, 4, true, GEGLU, false, MS, false, MS == 16, PIPE>(a, s);
 }
 // consumer of a folded LayerNorm: always a LINEAR GEMM
-template <int BM, int BN, bool GEGLU, int MS, int PIPE>
+template <int BM, int BN, bool GEGLU, int MS, int PIPE, int WM, int WN>
 int launch2ln(const IgemmArgs& a, hipStream_t s) {
-    return launch2<BM, BN, 4, 2, 4, false, GEGLU, false, MS, true, MS == 16, PIPE>(a, s);
+    return launch2<BM, BN, WM, WN, 4, false, GEGLU, false, MS, true, MS == 16, PIPE>(a, s);
 }
-// one tile configuration (all: 8 waves as 4 x 2, four-stage ring), any mode
-template <int BM, int BN, int MS, int PIPE>
+// one tile configuration (waves as WM x WN, four-stage ring), any mode
+template <int BM, int BN, int MS, int PIPE, int WM = 4, int WN = 2>
 int launch_tile(const IgemmArgs& a, hipStream_t s) {
     const bool g = a.act == ACT_GEGLU;
     if (a.ln_stats) {
-        if constexpr (BN == 256) { if (g) return launch2ln<BM, BN, true, MS, PIPE>(a, s); }
+        if constexpr (BN == 256) { if (g) return launch2ln<BM, BN, true, MS, PIPE, WM, WN>(a, s); }
         if constexpr (BN == 128) return FGDM_ERR_ARG;
-        else return launch2ln<BM, BN, false, MS, PIPE>(a, s);
+        else return launch2ln<BM, BN, false, MS, PIPE, WM, WN>(a, s);
     }
-    if constexpr (BN == 256) { if (g) return launch2m<BM, BN, true, MS, PIPE>(a, s); }
-    return launch2m<BM, BN, false, MS, PIPE>(a, s);
+    if constexpr (BN == 256) { if (g) return launch2m<BM, BN, true, MS, PIPE, WM, WN>(a, s); }
+    return launch2m<BM, BN, false, MS, PIPE, WM, WN>(a, s);
 }
 
 // out[m][n] = ((sum_s ws[s][m][n]) + bias + emb -> act) * scale + resid, fixed summation order
@@ -812,7 +812,9 @@ int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
-// cfg & 15: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320   6 = 256x128   (all: 8 waves, 4-stage ring, 16x16x32 MFMA)
+// cfg & 15: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320   6 = 256x128   (8 waves, 4-stage ring, 16x16x32 MFMA)
+//           7 = 64x160, four waves, two workgroups per CU: the linears of the 8x8 level (M = 64 rows per sample), whose grids
+//               cannot fill the chip with taller tiles
 //           3..5 = tiles 0..2 on the 32x32x16 MFMA (kept for A/B measurements)
 // cfg >> 4: K loop: 0 = the process default (FGDM_IGEMM_PIPE, default 1), 1 = the phase-locked loop, 2 = the software-pipelined one
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
@@ -824,7 +826,7 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     const size_t px = a.mode == IG_LINEAR ? (size_t)a.M : (size_t)a.B * a.H * a.W;
     const bool small = px * (size_t)std::max(a.C0, a.C1) * 2 < (1ull << 32) && (size_t)(a.N + 320) * a.K * 2 < (1ull << 32);
     const bool pipe = (psel == 0 ? pipe_default != 0 : psel == 2) && a.mode != IG_CONV3_UP2 && small;
-    const int bn = (tile == 1 || tile == 4) ? 256 : tile == 6 ? 128 : 320;
+    const int bn = (tile == 1 || tile == 4) ? 256 : tile == 6 ? 128 : tile == 7 ? 160 : 320;
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
     if (a.act == ACT_GEGLU && bn != 256) return FGDM_ERR_ARG;
     if (a.splitk > 1) {
@@ -844,6 +846,7 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
         case 4: return launch_tile<256, 256, 32, 0>(a, s);
         case 5: return launch_tile<128, 320, 32, 0>(a, s);
         case 6: return pipe ? launch_tile<256, 128, 16, 1>(a, s) : launch_tile<256, 128, 16, 0>(a, s);
+        case 7: return a.mode != IG_LINEAR ? FGDM_ERR_ARG : pipe ? launch_tile<64, 160, 16, 1, 2, 2>(a, s) : launch_tile<64, 160, 16, 0, 2, 2>(a, s);
         default: return FGDM_ERR_ARG;
     }
 }

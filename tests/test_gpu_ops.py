@@ -302,7 +302,7 @@ def test_linear_pipelined_kernel(lib):
         ref = F.linear(x, w2, b2)
         res = h16(rnd((M, N2), 74))
         resd = res.half().cuda()
-        for cfg in (4, 6, 7, 9):
+        for cfg in (4, 6, 7, 9, 11, 27):      # 11 / 27: the four-wave 64x160 tile, pipelined / phase-locked K loop
             lib.fgdm_debug_force_igemm_cfg(cfg)
             out = torch.empty(M, N2, dtype=torch.half, device='cuda')
             assert lib.fgdm_op_linear(_p(xd), _p(w2d), _p(b2d), _p(resd), M, K, N2, 0, 0, 0, 0, _p(out), _st()) == 0
@@ -353,6 +353,7 @@ LN_CASES = [
     (200, 320, 320, 320, 0, True, 0, -2),       # small problem: 2-stage kernel + the separate row-statistics pass (same 2 slots)
     (16384, 320, 320, 640, 0, True, 1, -2),     # the same shape as case 0 forced onto the 2-stage kernel
     (4100, 640, 640, 640, 0, False, 6, 4),      # ragged M on the 128x320 tiles
+    (2048, 1280, 1280, 1280, 0, True, 0, -8),   # the 8x8 level: 64x160 four-wave tiles (automatic), statistics from the separate pass
 ]
 
 
