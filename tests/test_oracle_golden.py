@@ -287,3 +287,16 @@ def test_adapt_unet_multi_adapter():
         assert relerr(onn.unet_forward(p, gi.SD_CFG, x, t, ctx, conds=conds, pcond=gi.get('adapt/control'), **kw),
                       g['eps_conds_control']) < 2e-5
         assert relerr(onn.unet_forward(p, gi.SD_CFG, x, t, ctx, **kw), g['eps_plain']) < 2e-5
+
+
+def test_full_size_fixture_is_certified_against_reference_apply_model():
+    """tests/golden/full_size*.npz hold what the reference's own ControlLDM.apply_model (controlnet/cldm/cldm.py:836-849) returns:
+    tools/make_goldens.py --only full_size_check re-ran the CFG pair at t = 981 through that method (the class itself, its heavy
+    LatentDiffusion constructor bypassed) in the build container and recorded the comparison next to the fixtures."""
+    import json
+    import os
+    from common import GOLD
+    for name in ('full_size', 'full_size_ac'):
+        rec = json.load(open(os.path.join(GOLD, name + '_apply_model_check.json')))
+        assert rec['bit_identical'] and rec['max_abs_diff'] == 0.0
+        assert 'ControlLDM.apply_model' in rec['through'] and rec['fixture'].startswith(name + '.npz')

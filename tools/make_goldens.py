@@ -646,6 +646,57 @@ def g_sampler_unet():
     save('sampler_unet', **arrs)
 
 
+def _reference_control_ldm(cn, cu):
+    """The reference's ControlLDM (controlnet/cldm/cldm.py:816-849) around already-built control / diffusion models: the heavy
+    LatentDiffusion constructor (first stage, text encoder: not on the path, need the network) is bypassed, the methods are the
+    reference's own -- so `apply_model` below IS ControlLDM.apply_model, not a re-wiring of it."""
+    from controlnet.cldm.cldm import ControlLDM
+
+    class Wrapper(nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.diffusion_model = m
+
+    class LDM(ControlLDM):
+        def __init__(s):
+            nn.Module.__init__(s)
+            s.model = Wrapper(cu)
+            s.control_model = cn
+            s.control_key = 'hint'
+            s.only_mid_control = False
+            s.control_scales = [1.0] * 13
+    return LDM()
+
+
+def g_full_size_check():
+    """Certifies tests/golden/full_size.npz against ControlLDM.apply_model itself without the 25 minutes of the
+    50-step trajectory: the CFG pair at t = 981 through the reference class must reproduce the stored fixture bit for bit."""
+    import json
+    from controlnet.cldm.cldm import ControlNet, ControlledUnetModel
+    cn = ControlNet(**ref_cfg(gi.SD_CFG, hint_channels=3)).eval()
+    load_synth(cn, 'control_model.')
+    cu = ControlledUnetModel(**ref_cfg(gi.SD_CFG)).eval()
+    load_synth(cu, 'model.diffusion_model.')
+    ldm = _reference_control_ldm(cn, cu)
+    x = torch.from_numpy(synth.latents(1, 64, 64, seed=42))
+    c = torch.from_numpy(synth.context(1, seed=43))
+    uc = torch.from_numpy(synth.context(1, seed=44))
+    hint = torch.from_numpy(synth.hint(1, 512, seed=45))
+    name = 'full_size' + AC_SUFFIX
+    want = np.load(os.path.join(GOLD, name + '.npz'))['eps_pair_t981']
+    with torch.no_grad():
+        got = ldm.apply_model(torch.cat([x, x]), torch.full((2,), 981, dtype=torch.long),
+                              {'c_concat': [torch.cat([hint, hint])], 'c_crossattn': [torch.cat([uc, c])]})
+    got = got.float().numpy()
+    diff = float(np.abs(got - want.astype(np.float32)).max())
+    rec = {'fixture': name + '.npz:eps_pair_t981', 'through': 'controlnet.cldm.cldm.ControlLDM.apply_model (cldm.py:836-849)',
+           'max_abs_diff': diff, 'bit_identical': bool(np.array_equal(got, want.astype(np.float32)))}
+    print('   ', rec)
+    assert diff == 0.0, rec
+    with open(os.path.join(GOLD, name + '_apply_model_check.json'), 'w') as f:
+        json.dump(rec, f, indent=1)
+
+
 def g_full_size():
     """G7: the metric's own workload at full size -- SD-v1.5-width ControlledUnetModel + ControlNet, latent 64x64,
     hint 512x512 -- through the reference's modules wired as ControlLDM.apply_model does (cldm.py:836-849):
@@ -661,13 +712,7 @@ def g_full_size():
     load_synth(cn, 'control_model.')
     cu = ControlledUnetModel(**ref_cfg(gi.SD_CFG)).eval()
     load_synth(cu, 'model.diffusion_model.')
-    scales = [1.0] * 13
-
-    def apply_model(x, t, cond):
-        ctx = torch.cat(cond['c_crossattn'], 1)
-        control = cn(x=x, hint=torch.cat(cond['c_concat'], 1), timesteps=t, context=ctx)
-        control = [c * s for c, s in zip(control, scales)]
-        return cu(x=x, timesteps=t, context=ctx, control=control, only_mid_control=False)
+    apply_model = _reference_control_ldm(cn, cu).apply_model      # the reference's own method body (cldm.py:836-849)
     x = torch.from_numpy(synth.latents(1, 64, 64, seed=42))
     c = torch.from_numpy(synth.context(1, seed=43))
     uc = torch.from_numpy(synth.context(1, seed=44))
@@ -711,12 +756,13 @@ def g_full_size():
 
 ALL = dict(schedule=g_schedule, ddpm_schedule=g_ddpm_schedule, param_keys=g_param_keys, ops=g_ops,
            unet_full=g_unet_full, controlnet_full=g_controlnet_full, small_nets=g_small_nets,
-           samplers=g_samplers, samplers2=g_samplers2, samplers3=g_samplers3, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip, adapt_unet=g_adapt_unet, full_size=g_full_size)
+           samplers=g_samplers, samplers2=g_samplers2, samplers3=g_samplers3, sampler_unet=g_sampler_unet, vae=g_vae, clip=g_clip, adapt_unet=g_adapt_unet, full_size=g_full_size,
+           full_size_check=g_full_size_check)
 
 
 # generators that are ALSO run with the reference's modules under the emulated torch.autocast("cuda") policy
 # (scripts/txt2img_fgdm_inference.py:212-217 wraps the whole sampling loop in it) -> tests/golden/<name>_ac.npz
-AC = ('ops', 'unet_full', 'controlnet_full', 'small_nets', 'sampler_unet', 'adapt_unet', 'vae', 'clip', 'full_size')
+AC = ('ops', 'unet_full', 'controlnet_full', 'small_nets', 'sampler_unet', 'adapt_unet', 'vae', 'clip', 'full_size', 'full_size_check')
 
 
 def main():
