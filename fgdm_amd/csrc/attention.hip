@@ -640,15 +640,15 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
     static const bool pp_on = !(getenv("FGDM_ATTN_PP") && atoi(getenv("FGDM_ATTN_PP")) == 0);
     if (pp_on && T >= 256 && Tk >= 256 && (d == 40 || d == 80)) {
         const dim3 grid2(((T + 255) / 256) * H * B), block2(512);
-        if (d == 40) hipLaunchKernelGGL(attn_pp_kernel<40>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
-        else hipLaunchKernelGGL(attn_pp_kernel<80>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        if (d == 40) FGDM_LAUNCH(attn_pp_kernel<40>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        else FGDM_LAUNCH(attn_pp_kernel<80>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
         return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
     }
     const dim3 grid(((T + 127) / 128) * H * B), block(256);
     switch (d) {
-        case 40: hipLaunchKernelGGL(attn_kernel<40>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
-        case 80: hipLaunchKernelGGL(attn_kernel<80>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
-        case 160: hipLaunchKernelGGL(attn_kernel<160>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
+        case 40: FGDM_LAUNCH(attn_kernel<40>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
+        case 80: FGDM_LAUNCH(attn_kernel<80>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
+        case 160: FGDM_LAUNCH(attn_kernel<160>, grid, block, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
         default: return FGDM_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;

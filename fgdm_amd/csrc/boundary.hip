@@ -40,7 +40,7 @@ __global__ void k_image_to_u8(const float* __restrict__ x, uint8_t* __restrict__
 }
 int image_to_u8(const float* x, uint8_t* y, int B, int C, int HW, int mode, hipStream_t s) {
     if (B <= 0 || C <= 0 || HW <= 0 || (mode != 0 && mode != 1)) return FGDM_ERR_ARG;
-    hipLaunchKernelGGL(k_image_to_u8, dim3(ew_grid((size_t)B * HW * C)), dim3(EW_BLOCK), 0, s, x, y, B, C, HW, mode);
+    FGDM_LAUNCH(k_image_to_u8, dim3(ew_grid((size_t)B * HW * C)), dim3(EW_BLOCK), 0, s, x, y, B, C, HW, mode);
     return LAUNCH_OK();
 }
 
@@ -84,7 +84,7 @@ __global__ void k_resize_linear_u8(const uint8_t* __restrict__ src, uint8_t* __r
 int resize_linear_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return FGDM_ERR_ARG;
     const double sy = 1.0 / ((double)Ho / (double)H), sx = 1.0 / ((double)Wo / (double)W);
-    hipLaunchKernelGGL(k_resize_linear_u8, dim3(ew_grid((size_t)B * Ho * Wo * C)), dim3(EW_BLOCK), 0, s, src, dst, B, H, W, C,
+    FGDM_LAUNCH(k_resize_linear_u8, dim3(ew_grid((size_t)B * Ho * Wo * C)), dim3(EW_BLOCK), 0, s, src, dst, B, H, W, C,
                        Ho, Wo, sy, sx);
     return LAUNCH_OK();
 }
@@ -101,6 +101,6 @@ __global__ void k_u8_to_hint(const uint8_t* __restrict__ src, float* __restrict_
 }
 int u8_to_hint(const uint8_t* src, float* dst, int B, int HW, int C, hipStream_t s) {
     if (B <= 0 || HW <= 0 || C <= 0) return FGDM_ERR_ARG;
-    hipLaunchKernelGGL(k_u8_to_hint, dim3(ew_grid((size_t)B * C * HW)), dim3(EW_BLOCK), 0, s, src, dst, B, HW, C);
+    FGDM_LAUNCH(k_u8_to_hint, dim3(ew_grid((size_t)B * C * HW)), dim3(EW_BLOCK), 0, s, src, dst, B, HW, C);
     return LAUNCH_OK();
 }

@@ -91,6 +91,7 @@ struct IgemmArgs {
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 void igemm_set_force_cfg(int cfg);   // process-wide override of the tile choice (0 = automatic)
+void igemm_set_pair_hint(int mult);  // launches recorded from now on will be fused `mult` at a time (grid size for the tile choice)
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s);
 int igemm_stats_slots(const IgemmArgs& a);    // > 0: igemm_launch(a) will fill a.stats_out with that many slots per row; 0: it cannot
 int row_stats_slots(int C);                   // slots per row the separate pass writes: C / 160 (the epilogue's layout) or 1
@@ -150,3 +151,26 @@ int ancestral_step(const float* x, const float* eps, float sqrt_recip, float sqr
                    float std, const float* noise, float* out, size_t n, hipStream_t s);
 
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return FGDM_ERR_HIP; } while (0)
+
+// ---------------------------------------------------------------- deferred launches (twin-layer grouped launches)
+// While the engine RECORDS (engine.hip: apply_model with FGDM_PAIR_LAUNCH), nothing is enqueued: every launch site goes through
+// FGDM_LAUNCH, which then stores a closure (arguments by value) in the engine's list instead; the engine replays the lists of the
+// UNet encoder and of a ControlNet in lockstep and fuses launches of the same pipelined-GEMM instantiation and grid into ONE
+// grouped launch (igemm2.hip: igemm2_pair_kernel; blockIdx.y selects the argument set), so that the half-empty grids of the
+// 16x16 / 8x8 levels fill the chip.  Each net's launches keep their order, so the results do not change by a bit.
+#include <functional>
+typedef int (*IgemmPairFn)(const IgemmArgs& a0, const IgemmArgs& a1, unsigned grid_x, hipStream_t s);
+bool fgdm_recording();
+void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key = nullptr, IgemmPairFn pair = nullptr,
+                 const IgemmArgs* ia = nullptr, unsigned grid_x = 0);
+#define FGDM_LAUNCH(kernel, grid, block, smem, stream, ...)                                                                  \
+    do {                                                                                                                     \
+        if (fgdm_recording()) {                                                                                              \
+            fgdm_record([=](hipStream_t fgdm_s_) -> int {                                                                    \
+                hipLaunchKernelGGL(kernel, grid, block, smem, fgdm_s_, __VA_ARGS__);                                         \
+                return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;                                             \
+            });                                                                                                              \
+        } else {                                                                                                             \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                              \
+        }                                                                                                                    \
+    } while (0)

@@ -22,7 +22,7 @@ __global__ void k_nchw_to_nhwc(const float* __restrict__ x, half_t* __restrict__
     }
 }
 int nchw_f32_to_nhwc_f16(const float* x, half_t* y, int B, int C, int HW, int Cpad, hipStream_t s) {
-    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(ew_grid((size_t)B * HW * Cpad)), dim3(EW_BLOCK), 0, s, x, y, B, C, HW, Cpad);
+    FGDM_LAUNCH(k_nchw_to_nhwc, dim3(ew_grid((size_t)B * HW * Cpad)), dim3(EW_BLOCK), 0, s, x, y, B, C, HW, Cpad);
     return LAUNCH_OK();
 }
 
@@ -30,7 +30,7 @@ __global__ void k_f32_to_f16(const float* __restrict__ x, half_t* __restrict__ y
     EW_LOOP(i, n) y[i] = (half_t)x[i];
 }
 int f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_f32_to_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, y, n);
+    FGDM_LAUNCH(k_f32_to_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, y, n);
     return LAUNCH_OK();
 }
 __global__ void k_nhwc_f16_to_nchw_f32(const half_t* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
@@ -44,7 +44,7 @@ __global__ void k_nhwc_f16_to_nchw_f32(const half_t* __restrict__ x, float* __re
     }
 }
 int nhwc_f16_to_nchw_f32(const half_t* x, float* y, int B, int C, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(k_nhwc_f16_to_nchw_f32, dim3(ew_grid((size_t)B * C * HW)), dim3(EW_BLOCK), 0, s, x, y, B, C, HW);
+    FGDM_LAUNCH(k_nhwc_f16_to_nchw_f32, dim3(ew_grid((size_t)B * C * HW)), dim3(EW_BLOCK), 0, s, x, y, B, C, HW);
     return LAUNCH_OK();
 }
 // y = fp16(SiLU(x)): the `emb_layers` input of a ResBlock (openaimodel.py:238-244) when `emb` is handed in from outside
@@ -52,7 +52,7 @@ __global__ void k_silu_f32_to_f16(const float* __restrict__ x, half_t* __restric
     EW_LOOP(i, n) { const float v = x[i]; y[i] = (half_t)silu_f(v); }
 }
 int silu_f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_silu_f32_to_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, y, n);
+    FGDM_LAUNCH(k_silu_f32_to_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, y, n);
     return LAUNCH_OK();
 }
 
@@ -86,10 +86,10 @@ int im2col3x3(const half_t* x, half_t* A, int B, int H, int W, int C, int stride
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     if (Kpad < 9 * C || (Kpad & 63)) return FGDM_ERR_ARG;
     if ((C & 7) == 0) {
-        hipLaunchKernelGGL(k_im2col<8>, dim3(ew_grid((size_t)B * Ho * Wo * (Kpad / 8))), dim3(EW_BLOCK), 0, s, x, A, B,
+        FGDM_LAUNCH(k_im2col<8>, dim3(ew_grid((size_t)B * Ho * Wo * (Kpad / 8))), dim3(EW_BLOCK), 0, s, x, A, B,
                            H, W, C, stride, Ho, Wo, Kpad);
     } else if ((C & 3) == 0) {
-        hipLaunchKernelGGL(k_im2col<4>, dim3(ew_grid((size_t)B * Ho * Wo * (Kpad / 4))), dim3(EW_BLOCK), 0, s, x, A, B,
+        FGDM_LAUNCH(k_im2col<4>, dim3(ew_grid((size_t)B * Ho * Wo * (Kpad / 4))), dim3(EW_BLOCK), 0, s, x, A, B,
                            H, W, C, stride, Ho, Wo, Kpad);
     } else {
         return FGDM_ERR_ARG;
@@ -118,7 +118,7 @@ __global__ void k_avgpool2(const half_t* __restrict__ x, half_t* __restrict__ y,
 }
 int avgpool2(const half_t* x, half_t* y, int B, int H, int W, int C, hipStream_t s) {
     if ((C & 7) || (H & 1) || (W & 1)) return FGDM_ERR_ARG;
-    hipLaunchKernelGGL(k_avgpool2, dim3(ew_grid((size_t)B * (H / 2) * (W / 2) * (C / 8))), dim3(EW_BLOCK), 0, s, x, y, B, H, W, C);
+    FGDM_LAUNCH(k_avgpool2, dim3(ew_grid((size_t)B * (H / 2) * (W / 2) * (C / 8))), dim3(EW_BLOCK), 0, s, x, y, B, H, W, C);
     return LAUNCH_OK();
 }
 
@@ -133,7 +133,7 @@ __global__ void k_add_f16(const half_t* __restrict__ a, const half_t* __restrict
 }
 int add_f16(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s) {
     if (n & 7) return FGDM_ERR_ARG;
-    hipLaunchKernelGGL(k_add_f16, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, s, a, b, y, n / 8);
+    FGDM_LAUNCH(k_add_f16, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, s, a, b, y, n / 8);
     return LAUNCH_OK();
 }
 
@@ -143,7 +143,7 @@ __global__ void k_add_f16_to_f32(const float* __restrict__ a, const half_t* __re
     EW_LOOP(i, n) y[i] = a[i] + (float)b[i];
 }
 int add_f16_to_f32(const float* a, const half_t* b, float* y, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_add_f16_to_f32, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, b, y, n);
+    FGDM_LAUNCH(k_add_f16_to_f32, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, b, y, n);
     return LAUNCH_OK();
 }
 
@@ -164,7 +164,7 @@ __global__ void k_timestep_embed(const int64_t* __restrict__ t, const float* __r
     }
 }
 int timestep_embed(const int64_t* t, const float* tf, half_t* y, int B, int dim, int rows_pad, hipStream_t s) {
-    hipLaunchKernelGGL(k_timestep_embed, dim3(ew_grid((size_t)rows_pad * dim)), dim3(EW_BLOCK), 0, s, t, tf, y, B, dim, rows_pad);
+    FGDM_LAUNCH(k_timestep_embed, dim3(ew_grid((size_t)rows_pad * dim)), dim3(EW_BLOCK), 0, s, t, tf, y, B, dim, rows_pad);
     return LAUNCH_OK();
 }
 
@@ -179,7 +179,7 @@ __global__ void k_transpose_pad(const half_t* __restrict__ v, half_t* __restrict
     }
 }
 int transpose_pad_keys(const half_t* v, half_t* vt, int B, int Tk, int C, int Tkpad, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_pad, dim3(ew_grid((size_t)B * C * Tkpad)), dim3(EW_BLOCK), 0, s, v, vt, B, Tk, C, Tkpad);
+    FGDM_LAUNCH(k_transpose_pad, dim3(ew_grid((size_t)B * C * Tkpad)), dim3(EW_BLOCK), 0, s, v, vt, B, Tk, C, Tkpad);
     return LAUNCH_OK();
 }
 
@@ -206,7 +206,7 @@ __global__ void k_ddim_step(const float* __restrict__ x, const float* __restrict
 int ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale, float a_t, float a_prev,
               float sigma_t, float sqrt_one_minus_at, const float* noise, float* x_prev, float* pred_x0, float* e_out,
               size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_ddim_step, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, e_cond, e_uncond, cfg_scale, a_t, a_prev,
+    FGDM_LAUNCH(k_ddim_step, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, e_cond, e_uncond, cfg_scale, a_t, a_prev,
                        sigma_t, sqrt_one_minus_at, noise, x_prev, pred_x0, e_out, n);
     return LAUNCH_OK();
 }
@@ -225,7 +225,7 @@ __global__ void k_plms(const float* __restrict__ e, const float* __restrict__ e1
 int plms_combine(const float* e_t, const float* e1, const float* e2, const float* e3, int order, float* e_prime,
                  size_t n, hipStream_t s) {
     if (order < 1 || order > 3) return FGDM_ERR_ARG;
-    hipLaunchKernelGGL(k_plms, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, e_t, e1, e2, e3, order, e_prime, n);
+    FGDM_LAUNCH(k_plms, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, e_t, e1, e2, e3, order, e_prime, n);
     return LAUNCH_OK();
 }
 
@@ -234,7 +234,7 @@ __global__ void k_axpby(const float* __restrict__ a, float ca, const float* __re
     EW_LOOP(i, n) y[i] = ca * a[i] + (b ? cb * b[i] : 0.f);
 }
 int axpby(const float* a, float ca, const float* b, float cb, float* y, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_axpby, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, ca, b, cb, y, n);
+    FGDM_LAUNCH(k_axpby, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, ca, b, cb, y, n);
     return LAUNCH_OK();
 }
 
@@ -244,7 +244,7 @@ __global__ void k_mask_blend(const float* __restrict__ a, const float* __restric
     EW_LOOP(i, n) y[i] = a[i] * m[i] + (1.0f - m[i]) * b[i];
 }
 int mask_blend(const float* a, const float* b, const float* m, float* y, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_mask_blend, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, b, m, y, n);
+    FGDM_LAUNCH(k_mask_blend, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, a, b, m, y, n);
     return LAUNCH_OK();
 }
 
@@ -260,7 +260,7 @@ __global__ void k_ancestral(const float* __restrict__ x, const float* __restrict
 }
 int ancestral_step(const float* x, const float* eps, float sqrt_recip, float sqrt_recipm1, float coef1, float coef2,
                    float std, const float* noise, float* out, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_ancestral, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, eps, sqrt_recip, sqrt_recipm1, coef1,
+    FGDM_LAUNCH(k_ancestral, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, x, eps, sqrt_recip, sqrt_recipm1, coef1,
                        coef2, std, noise, out, n);
     return LAUNCH_OK();
 }
@@ -288,7 +288,7 @@ __global__ void k_vae_prequant(const float* __restrict__ z, const float* __restr
     }
 }
 int vae_prequant(const float* z, const float* wb, float scale, half_t* y, int B, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(k_vae_prequant, dim3(ew_grid((size_t)B * HW)), dim3(EW_BLOCK), 0, s, z, wb, scale, y, B, HW);
+    FGDM_LAUNCH(k_vae_prequant, dim3(ew_grid((size_t)B * HW)), dim3(EW_BLOCK), 0, s, z, wb, scale, y, B, HW);
     return LAUNCH_OK();
 }
 
@@ -317,6 +317,6 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
 }
 int softmax_rows(const float* S, half_t* P, int rows, int cols, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return FGDM_ERR_ARG;
-    hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, s, S, P, cols);
+    FGDM_LAUNCH(k_softmax_rows, dim3(rows), dim3(256), 0, s, S, P, cols);
     return LAUNCH_OK();
 }

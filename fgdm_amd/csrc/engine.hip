@@ -180,6 +180,20 @@ static int roundup(int x, int m) { return (x + m - 1) / m * m; }
 // (the same stream the kernels run on), so per-kernel-class device time, launch counts and the ALGORITHMIC
 // flops / bytes of exactly those launches can be read back without an external profiler.
 enum ProfClass { PC_IGEMM = 0, PC_ATTN = 1, PC_NORM = 2, PC_ELEM = 3, PC_COUNT = 4 };
+// ---- deferred launches (common.h): one op per launch / copy / profiler bracket edge of a recorded network walk
+struct RecOp {
+    enum Kind { RUN, PROF_BEGIN, PROF_END } kind = RUN;
+    std::function<int(hipStream_t)> run;
+    const void* pair_key = nullptr;      // RUN of a pipelined-GEMM instantiation that has a two-problem twin
+    IgemmPairFn pair = nullptr;
+    IgemmArgs ia{};
+    unsigned grid_x = 0;
+    int cls = 0;                         // PROF_BEGIN
+    double w = 0, bytes = 0;
+    char tag[56] = {0};
+};
+thread_local std::vector<RecOp>* g_rec = nullptr;
+
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> pool;
@@ -197,7 +211,15 @@ struct Prof {
     int stride = 1;
     long counter = 0;
     bool armed = false;
-    void begin(int cls, hipStream_t s, double w, const char* tag = "") {
+    // bytes: algorithmic HBM bytes of the bracketed launch (counted only when the bracket is taken)
+    void begin(int cls, hipStream_t s, double w, const char* tag = "", double nbytes = 0.0) {
+        if (g_rec) {                                  // recording: the bracket becomes two ops around the launch it encloses
+            if (!on) return;
+            RecOp o; o.kind = RecOp::PROF_BEGIN; o.cls = cls; o.w = w; o.bytes = nbytes;
+            snprintf(o.tag, sizeof(o.tag), "%s", tag);
+            g_rec->push_back(std::move(o));
+            return;
+        }
         armed = false;
         if (!on || (counter++ % stride) != 0) return;
         armed = true;
@@ -208,8 +230,15 @@ struct Prof {
         snprintf(r.tag, sizeof(r.tag), "%s", tag);
         recs.push_back(r);
         work[cls] += w;
+        bytes[cls] += nbytes;
     }
     void end(hipStream_t s) {
+        if (g_rec) {
+            if (!on) return;
+            RecOp o; o.kind = RecOp::PROF_END;
+            g_rec->push_back(std::move(o));
+            return;
+        }
         if (!on || !armed || recs.empty()) return;
         armed = false;
         hipEvent_t e = get();
@@ -220,6 +249,15 @@ struct Prof {
 };
 
 }  // namespace
+
+bool fgdm_recording() { return g_rec != nullptr; }
+void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key, IgemmPairFn pair, const IgemmArgs* ia, unsigned grid_x) {
+    RecOp o;
+    o.run = std::move(run);
+    o.pair_key = pair_key; o.pair = pair; o.grid_x = grid_x;
+    if (ia) o.ia = *ia;
+    g_rec->push_back(std::move(o));
+}
 
 #define CHK0(x) do { int _rc0 = (x); if (_rc0 != FGDM_OK) return _rc0; } while (0)
 struct fgdm_engine {
@@ -255,6 +293,10 @@ struct fgdm_engine {
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool twin_streams = false;
+    // FGDM_PAIR_LAUNCH (default on): the UNet encoder + middle block and the ControlNets are RECORDED (common.h, "deferred
+    // launches") and replayed in lockstep on the one stream, twin GEMM launches fused into grouped launches (replay_zip)
+    bool pair_launch = true;
+    long paired_launches = 0, replayed_launches = 0;
     struct Deferred { const GemmW* w; Tensor src; int idx; float scale; };
     Prof prof;
 
@@ -838,6 +880,25 @@ struct fgdm_engine {
     }
 
     // ------------------------------------------------------------------------------------ runtime helpers
+    // device-to-device copy / memset on the call's stream, deferred like every launch while a walk is being recorded
+    int dcopy(void* dst, const void* src, size_t bytes) {
+        if (g_rec) {
+            RecOp o;
+            o.run = [=](hipStream_t rs) -> int { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rs) == hipSuccess ? FGDM_OK : FGDM_ERR_HIP; };
+            g_rec->push_back(std::move(o));
+            return FGDM_OK;
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+    }
+    int dzero(void* dst, size_t bytes) {
+        if (g_rec) {
+            RecOp o;
+            o.run = [=](hipStream_t rs) -> int { return hipMemsetAsync(dst, 0, bytes, rs) == hipSuccess ? FGDM_OK : FGDM_ERR_HIP; };
+            g_rec->push_back(std::move(o));
+            return FGDM_OK;
+        }
+        return hipMemsetAsync(dst, 0, bytes, s) == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+    }
     Tensor talloc(int B, int H, int W, int C) {
         Tensor t; t.B = B; t.H = H; t.W = W; t.C = C;
         t.p = (half_t*)ar->alloc(t.numel() * sizeof(half_t));
@@ -902,12 +963,13 @@ struct fgdm_engine {
             if (!e.stats->p) return fail(FGDM_ERR_NOMEM, "workspace (LayerNorm statistics)");
             if (e.stats->slots) a.stats_out = e.stats->p;
         }
-        prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real, tag);
-        if (prof.armed) {   // operands once: activations + weights + residual + output
+        double nbytes = 0.0;
+        if (prof.on) {      // operands once: activations + weights + residual + output
             const double in_b = 2.0 * ((double)x0.numel() + (x1 ? (double)x1->numel() : 0.0));
             const double out_b = (double)a.M * nout * (e.out_kind == OUT_F16 || e.out_kind == OUT_F16_T ? 2.0 : 4.0);
-            prof.bytes[PC_IGEMM] += in_b + 2.0 * (double)w.N * w.K + out_b + (e.resid ? 2.0 * (double)a.M * nout : 0.0);
+            nbytes = in_b + 2.0 * (double)w.N * w.K + out_b + (e.resid ? 2.0 * (double)a.M * nout : 0.0);
         }
+        prof.begin(PC_IGEMM, s, 2.0 * (double)a.M * (double)w.N * (double)w.k_real, tag, nbytes);
         int rc = igemm_launch(a, s);
         prof.end(s);
         if (a.ws) ar->release(a.ws);
@@ -1023,7 +1085,7 @@ struct fgdm_engine {
             *v2t = talloc(B, 1, C, Tkp);
             if (!v2t->p) return fail(FGDM_ERR_NOMEM, "workspace");
         }
-        if (Tkp != Tk) HIP_TRY(hipMemsetAsync(v2t->p, 0, v2t->numel() * sizeof(half_t), s));
+        if (Tkp != Tk) CHK(dzero(v2t->p, v2t->numel() * sizeof(half_t)));
         { Epi e; e.out_kind = OUT_F16_T; e.out = v2t->p; e.ld_out = Tkp; e.rps = Tk; CHK(linear(l.v2, ctx16, e, nullptr)); }
         return FGDM_OK;
     }
@@ -1080,7 +1142,7 @@ struct fgdm_engine {
         qk = talloc(B, x.H, x.W, 2 * C);
         vt = talloc(B, 1, C, Tp);
         if (!qk.p || !vt.p) return fail(FGDM_ERR_NOMEM, "workspace");
-        if (Tp != T) HIP_TRY(hipMemsetAsync(vt.p, 0, vt.numel() * sizeof(half_t), s));
+        if (Tp != T) CHK(dzero(vt.p, vt.numel() * sizeof(half_t)));
         { Epi e; if (ln_fold) e.ln = &s1; e.out = qk.p; e.ld_out = 2 * C; e.rps = T;
           e.out2 = vt.p; e.out_kind2 = OUT_F16_T; e.ld_out2 = Tp; e.split_n = 2 * C;
           CHK(linear(l.qkv1, a1, e, nullptr)); }
@@ -1106,8 +1168,8 @@ struct fgdm_engine {
             const size_t sb = (size_t)(B / 2) * T * s2.slots * 2 * sizeof(float);
             float* s2f = (float*)ar->alloc(2 * sb);
             if (!s2f) return fail(FGDM_ERR_NOMEM, "workspace");
-            HIP_TRY(hipMemcpyAsync(s2f, s2.p, sb, hipMemcpyDeviceToDevice, s));
-            HIP_TRY(hipMemcpyAsync((char*)s2f + sb, s2.p, sb, hipMemcpyDeviceToDevice, s));
+            CHK(dcopy(s2f, s2.p, sb));
+            CHK(dcopy((char*)s2f + sb, s2.p, sb));
             ar->release(s2.p); s2.p = s2f;
         }
         // --- attn2 (cross, 77-token context), norm2 folded into to_q
@@ -1155,8 +1217,8 @@ struct fgdm_engine {
         *full = talloc(2 * h.B, h.H, h.W, h.C);
         if (!full->p) return fail(FGDM_ERR_NOMEM, "workspace");
         const size_t bytes = h.numel() * sizeof(half_t);
-        HIP_TRY(hipMemcpyAsync(full->p, h.p, bytes, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync((char*)full->p + bytes, h.p, bytes, hipMemcpyDeviceToDevice, s));
+        CHK(dcopy(full->p, h.p, bytes));
+        CHK(dcopy((char*)full->p + bytes, h.p, bytes));
         return FGDM_OK;
     }
     // block_fwd for a block whose input is the SHARED half batch (FGDM_FLAG_CFG_PAIRS): layers run on B/2 rows until the
@@ -1408,6 +1470,66 @@ struct fgdm_engine {
     // ControlNet.forward (cldm.py:792-813).  fused = true: every zero-conv output is scaled and ADDED in place into
     // the UNet's skip tensor hs[i] / h_mid (cldm.py:40,46 + :846), so control residuals never hit HBM separately.
     // fused = false: raw residuals are written as fp32 NCHW into out32 (test entry).
+    // ---- replay of recorded walks
+    int run_op(RecOp& o) {
+        switch (o.kind) {
+            case RecOp::PROF_BEGIN: prof.begin(o.cls, s, o.w, o.tag, o.bytes); return FGDM_OK;
+            case RecOp::PROF_END: prof.end(s); return FGDM_OK;
+            default: ++replayed_launches; return o.run(s);
+        }
+    }
+    // a unit = one op, or a profiler bracket around exactly one launch; `launch` = index of its fusable launch or -1
+    struct Unit { size_t first, last; long launch; };
+    static Unit unit_at(std::vector<RecOp>& v, size_t i) {
+        if (v[i].kind == RecOp::PROF_BEGIN && i + 2 < v.size() + 0 && v[i + 1].kind == RecOp::RUN && v[i + 2].kind == RecOp::PROF_END)
+            return Unit{i, i + 2, v[i + 1].pair ? (long)(i + 1) : -1};
+        if (v[i].kind == RecOp::RUN) return Unit{i, i, v[i].pair ? (long)i : -1};
+        return Unit{i, i, -1};
+    }
+    int run_unit(std::vector<RecOp>& v, const Unit& u) {
+        for (size_t k = u.first; k <= u.last; ++k) CHK(run_op(v[k]));
+        return FGDM_OK;
+    }
+    // Two recorded walks, replayed in lockstep: each list keeps its order (the nets are independent of each other); a fusable GEMM
+    // launch of A is fused with the next launch of B of the same instantiation and grid found within a short look-ahead
+    int replay_zip(std::vector<RecOp>& A, std::vector<RecOp>& B) {
+        size_t i = 0, j = 0;
+        constexpr int LOOK = 24;
+        while (i < A.size()) {
+            const Unit ua = unit_at(A, i);
+            long partner = -1;
+            Unit ub{0, 0, -1};
+            if (ua.launch >= 0) {
+                size_t jj = j;
+                for (int d = 0; d < LOOK && jj < B.size(); ++d) {
+                    const Unit u = unit_at(B, jj);
+                    if (u.launch >= 0 && B[u.launch].pair_key == A[ua.launch].pair_key && B[u.launch].grid_x == A[ua.launch].grid_x) {
+                        partner = (long)jj; ub = u;
+                        break;
+                    }
+                    jj = u.last + 1;
+                }
+            }
+            if (partner < 0) { CHK(run_unit(A, ua)); i = ua.last + 1; continue; }
+            while (j < (size_t)partner) { const Unit u = unit_at(B, j); CHK(run_unit(B, u)); j = u.last + 1; }
+            // fused: one bracket (both problems' work), one launch
+            RecOp& la = A[ua.launch];
+            RecOp& lb = B[ub.launch];
+            const bool ba = ua.first != ua.last, bb = ub.first != ub.last;
+            if (ba || bb) {
+                RecOp& pa = ba ? A[ua.first] : B[ub.first];
+                prof.begin(pa.cls, s, (ba ? A[ua.first].w : 0.0) + (bb ? B[ub.first].w : 0.0), pa.tag,
+                           (ba ? A[ua.first].bytes : 0.0) + (bb ? B[ub.first].bytes : 0.0));
+            }
+            CHK(la.pair(la.ia, lb.ia, la.grid_x, s));
+            if (ba || bb) prof.end(s);
+            ++paired_launches; replayed_launches += 1;
+            i = ua.last + 1; j = ub.last + 1;
+        }
+        while (j < B.size()) { const Unit u = unit_at(B, j); CHK(run_unit(B, u)); j = u.last + 1; }
+        return FGDM_OK;
+    }
+
     // dst <- dst + scale (W src + b), in place (cldm.py:40,46,846 fused into the zero-conv's epilogue)
     int zero_conv_into(const GemmW& zw, const Tensor& src, Tensor& dst, float scale) {
         Epi e;
@@ -1529,6 +1651,26 @@ struct fgdm_engine {
         const bool with_cn = !cns.empty() && !(flags & FGDM_FLAG_NO_CONTROL);
         const bool twin = twin_streams && with_cn && s2 && !(flags & FGDM_FLAG_ONLY_MID_CONTROL);
         std::vector<Deferred> deferred;
+        // ---- grouped twin launches: record the ControlNet walks now, the UNet encoder + middle block below, replay them together
+        const bool paired = pair_launch && with_cn && !twin && !(flags & FGDM_FLAG_ONLY_MID_CONTROL);
+        std::vector<std::vector<RecOp>> rec_cn(paired ? cns.size() : 0);
+        std::vector<RecOp> rec_un;
+        struct RecGuard { ~RecGuard() { g_rec = nullptr; igemm_set_pair_hint(1); } } rec_guard;   // whatever path leaves: recording ends
+        if (paired) {
+            static const bool fat = !(getenv("FGDM_PAIR_FAT_TILES") && atoi(getenv("FGDM_PAIR_FAT_TILES")) == 0);       // A/B knob
+            if (fat) igemm_set_pair_hint(2);
+            ar = &arena2;
+            int rc = FGDM_OK;
+            for (size_t c = 0; c < cns.size() && rc == FGDM_OK; ++c) {
+                g_rec = &rec_cn[c];
+                rc = controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, nullptr, nullptr, false, nullptr, 0, pairs,
+                                    &deferred);
+            }
+            g_rec = nullptr;
+            ar = &arena;
+            if (rc != FGDM_OK) return rc;
+            g_rec = &rec_un;
+        }
         if (twin) {
             if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, ev_fork, 0) != hipSuccess) return fail(FGDM_ERR_HIP, "stream fork");
             hipStream_t main_s = s;
@@ -1577,8 +1719,18 @@ struct fgdm_engine {
         Tensor hm;
         CHK(block_fwd(n.middle, h, false, nullptr, ec, ctx16, nullptr, &hm));
         // ---- ControlNets: residuals accumulate in place into hs / hm (cldm.py:40,46,846)
-        if (twin) {
-            if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return fail(FGDM_ERR_HIP, "stream join");
+        if (paired) {
+            g_rec = nullptr;
+            igemm_set_pair_hint(1);
+            // UNet with the first ControlNet, further ControlNets with each other
+            CHK(replay_zip(rec_un, rec_cn[0]));
+            for (size_t c = 1; c < rec_cn.size(); c += 2) {
+                std::vector<RecOp> none;
+                CHK(replay_zip(rec_cn[c], c + 1 < rec_cn.size() ? rec_cn[c + 1] : none));
+            }
+        }
+        if (twin || paired) {
+            if (twin && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return fail(FGDM_ERR_HIP, "stream join");
             for (const Deferred& d : deferred) CHK(zero_conv_into(*d.w, d.src, d.idx < 0 ? hm : hs[d.idx], d.scale));
             // the ControlNets' block outputs go back to their own arena: its next user is the next call's second stream, which
             // waits for that call's fork event, recorded behind these zero-convs
@@ -1844,6 +1996,7 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
         return rc;
     }
     if (const char* v = getenv("FGDM_TWIN_STREAMS")) e->twin_streams = atoi(v) != 0;
+    if (const char* v = getenv("FGDM_PAIR_LAUNCH")) e->pair_launch = atoi(v) != 0;
     if (e->twin_streams && !e->cns.empty()) {
         if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1866,6 +2019,8 @@ void fgdm_destroy(fgdm_engine* e) {
     for (auto& n : e->cns) if (n.guided.p) (void)hipFree(n.guided.p);
     e->drop_context();
     e->drop_adapter_conds();
+    if (getenv("FGDM_PAIR_DEBUG") && e->replayed_launches)
+        fprintf(stderr, "[fgdm] grouped twin launches: %ld of %ld replayed launches were fused pairs\n", e->paired_launches, e->replayed_launches);
     if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);

@@ -310,7 +310,7 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(WM * WN * 64), smem, s, a);
+    FGDM_LAUNCH(k, dim3(ntm * ntn), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
@@ -319,6 +319,10 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 // 2-stage kernel above with the tile of lowest modelled time.
 static int g_force_cfg = 0;
 void igemm_set_force_cfg(int cfg) { g_force_cfg = cfg; }
+// > 1 while the engine records a walk whose GEMM launches will be fused with their twins of another net (common.h, "deferred
+// launches"): the grid a tile choice is judged by is that many times the single problem's
+static thread_local int g_pair_mult = 1;
+void igemm_set_pair_hint(int mult) { g_pair_mult = mult > 1 ? mult : 1; }
 
 // tile configuration for `a` (0 = the 2-stage kernel picks one of its own tiles; 4 + c = pipelined kernel cfg c: tile c & 15 =
 // 0..6, K loop c >> 4, see igemm2_launch)
@@ -335,7 +339,7 @@ static int pick_force(const IgemmArgs& a) {
         if (!geglu && a.N % 320 == 0) {
             const long b256 = (long)((a.M + 255) / 256) * (a.N / 320);
             const long b128 = (long)((a.M + 127) / 128) * (a.N / 320);
-            if (b256 >= 192) force = 4;
+            if (b256 * g_pair_mult >= 192) force = 4;
             else if (b128 >= 96) force = 6;
             else if (a.mode == IG_LINEAR && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && small_tiles &&
                      (long)((a.M + 63) / 64) * (a.N / 160) >= 128) force = 11;     // 64x160 tiles: the 8x8 level's linears

@@ -67,7 +67,7 @@ constexpr int RV_MAX = 6;       // per-sample emb rows staged in LDS per tile (m
 // PIPE: 0 = every K-step reads its 14 fragments, then runs its 40 MFMAs (all eight waves in the same phase); 1 = software-pipelined
 // K loop (see there).  ABL: the ablation switches of IgemmArgs::debug exist only in the instantiations tools/bench_igemm.py asks for.
 template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH, int PIPE, bool ABL>
-__global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
+__device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
     constexpr int NW = WM * WN, T = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / MS, NI = TN / MS;
@@ -692,6 +692,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a)
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH, int PIPE, bool ABL>
+__global__ __launch_bounds__(WM * WN * 64) void igemm2_kernel(const IgemmArgs a) {
+    igemm2_body<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH, PIPE, ABL>(a);
+}
+// Two problems of the same instantiation and grid in ONE launch (twin layers of the UNet encoder and a ControlNet: common.h,
+// "deferred launches"): blockIdx.y selects the argument set, everything else is the kernel above.
+struct IgemmArgs2 { IgemmArgs g[2]; };
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH, int PIPE, bool ABL>
+__global__ __launch_bounds__(WM * WN * 64) void igemm2_pair_kernel(const IgemmArgs2 p) {
+    igemm2_body<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH, PIPE, ABL>(p.g[blockIdx.y]);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH, int PIPE, bool ABL>
 int launch2p(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * ROWB;
     constexpr int smem = ring + (1 + RV_MAX) * BN * 4 + (2 * BM + BN) * 4;      // + staged bias, emb rows, LayerNorm (mean, rstd), u
@@ -703,7 +715,34 @@ int launch2p(const IgemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL(k, dim3(ntm * ntn * (SPLIT ? a.splitk : 1)), dim3(WM * WN * 64), smem, s, a);
+    const unsigned gx = (unsigned)(ntm * ntn * (SPLIT ? a.splitk : 1));
+    if (fgdm_recording()) {
+        auto single = [=](hipStream_t rs) -> int {
+            hipLaunchKernelGGL(k, dim3(gx), dim3(WM * WN * 64), smem, rs, a);
+            return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+        };
+        // the hot instantiations (pipelined loop, straight-line epilogue) have a twin that takes two argument sets
+        if constexpr (PIPE == 1 && PATH != 0 && !SPLIT && !ABL && MS == 16) {
+            static bool pair_attr_set = false;
+            auto kp = igemm2_pair_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH, PIPE, ABL>;
+            if (!pair_attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                pair_attr_set = true;
+            }
+            IgemmPairFn pf = [](const IgemmArgs& a0, const IgemmArgs& a1, unsigned grid_x, hipStream_t rs) -> int {
+                IgemmArgs2 p2;
+                p2.g[0] = a0; p2.g[1] = a1;
+                hipLaunchKernelGGL((igemm2_pair_kernel<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH, PIPE, ABL>), dim3(grid_x, 2),
+                                   dim3(WM * WN * 64), smem, rs, p2);
+                return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+            };
+            fgdm_record(single, (const void*)kp, pf, &a, gx);
+        } else {
+            fgdm_record(single);
+        }
+        return FGDM_OK;
+    }
+    hipLaunchKernelGGL(k, dim3(gx), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 // Which epilogue PATH serves `a` (see igemm2_kernel): 1 / 2 need the fp16 row-major output without an activation (GEGLU is
@@ -808,7 +847,7 @@ int igemm_splitk_factor(const IgemmArgs& a) {
 int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
     const size_t total4 = (size_t)a.M * a.N / 4;
     const int grid = (int)std::min<size_t>(2048, (total4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, a);
+    FGDM_LAUNCH(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 

@@ -273,9 +273,9 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
                     return FGDM_ERR_HIP;
                 attr_set = true;
             }
-            if (NT == 512) hipLaunchKernelGGL(gn_fused_kernel<512>, dim3(32 / NG, B), dim3(512), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma,
+            if (NT == 512) FGDM_LAUNCH(gn_fused_kernel<512>, dim3(32 / NG, B), dim3(512), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma,
                                               beta, silu, out);
-            else hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(32 / NG, B), dim3(256), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma, beta,
+            else FGDM_LAUNCH(gn_fused_kernel<256>, dim3(32 / NG, B), dim3(256), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma, beta,
                                     silu, out);
             return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
         }
@@ -284,7 +284,7 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
     const int nchunk = (HW + ppc - 1) / ppc;
     float* partial = ws;
     const int P = C >> 3, PI = P <= 256 ? 256 / P : 1;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), (size_t)PI * C * 2 * sizeof(float), s, x0, C0, x1,
+    FGDM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(256), (size_t)PI * C * 2 * sizeof(float), s, x0, C0, x1,
                        C1, HW, partial, ppc);
     const float inv_count = 1.0f / ((float)HW * (float)(C / 32));
     const size_t total = (size_t)HW * (C >> 3);
@@ -294,7 +294,7 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
     const int cap = 256 / (B < 8 ? B : 8);
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), (2 * C + 64) * sizeof(float), s, x0, C0, x1, C1, HW,
+    FGDM_LAUNCH(gn_apply_kernel, dim3(gx, B), dim3(256), (2 * C + 64) * sizeof(float), s, x0, C0, x1, C1, HW,
                        partial, nchunk, inv_count, eps, gamma, beta, silu, out);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
@@ -353,9 +353,9 @@ int layernorm_launch(const half_t* x, int rows, int C, const float* gamma, const
                      half_t* out, hipStream_t s) {
     if ((C & 7) || C > 2048 || rows <= 0) return FGDM_ERR_ARG;
     const dim3 grid((rows + 3) / 4), block(256);
-    if (C <= 512) hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
-    else if (C <= 1024) hipLaunchKernelGGL(ln_kernel<2>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
-    else hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
+    if (C <= 512) FGDM_LAUNCH(ln_kernel<1>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
+    else if (C <= 1024) FGDM_LAUNCH(ln_kernel<2>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
+    else FGDM_LAUNCH(ln_kernel<4>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
@@ -392,8 +392,8 @@ int layernorm32_launch(const float* x, int rows, int C, const float* gamma, cons
                        float* out32, hipStream_t s) {
     if ((C & 3) || rows <= 0 || (!out16 == !out32)) return FGDM_ERR_ARG;
     const dim3 grid((rows + 3) / 4), block(256);
-    if (out16) hipLaunchKernelGGL(ln32_kernel<half_t>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out16);
-    else hipLaunchKernelGGL(ln32_kernel<float>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out32);
+    if (out16) FGDM_LAUNCH(ln32_kernel<half_t>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out16);
+    else FGDM_LAUNCH(ln32_kernel<float>, grid, block, 0, s, x, rows, C, gamma, beta, eps, out32);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
@@ -424,6 +424,6 @@ int row_stats_launch(const half_t* x, int rows, int C, float* stats, hipStream_t
     if ((C & 7) || rows <= 0) return FGDM_ERR_ARG;
     const int slots = row_stats_slots(C);
     const size_t n = (size_t)rows * slots;
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, rows, C, slots, stats);
+    FGDM_LAUNCH(row_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, rows, C, slots, stats);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }

@@ -25,7 +25,7 @@ int embed_tokens(const int64_t* ids, const float* tok, const float* pos, float* 
                  hipStream_t s) {
     if (rows <= 0 || T <= 0 || (W & 7) || vocab <= 0) return FGDM_ERR_ARG;
     size_t g = ((size_t)rows * (W >> 2) + 255) / 256;
-    hipLaunchKernelGGL(k_embed_tokens, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, ids, tok, pos, out, rows, T, W, vocab);
+    FGDM_LAUNCH(k_embed_tokens, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, ids, tok, pos, out, rows, T, W, vocab);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
@@ -34,7 +34,7 @@ __global__ void k_f16_to_f32(const half_t* __restrict__ x, float* __restrict__ y
 }
 int f16_to_f32(const half_t* x, float* y, size_t n, hipStream_t s) {
     size_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(k_f16_to_f32, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s, x, y, n);
+    FGDM_LAUNCH(k_f16_to_f32, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s, x, y, n);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
@@ -108,6 +108,6 @@ int small_attention_launch(const half_t* qkv, int ld, int koff, int voff, half_t
             return FGDM_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(heads, B), dim3(256), smem, s, qkv, ld, koff, voff, out, ldo, T, causal, 1.0f / sqrtf((float)d));
+    FGDM_LAUNCH(k, dim3(heads, B), dim3(256), smem, s, qkv, ld, koff, voff, out, ldo, T, causal, 1.0f / sqrtf((float)d));
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }

@@ -367,3 +367,38 @@ def test_broadcast_layout_is_bit_identical_to_fp32_load():
             e.close()
     assert any(d == torch.float16 for d in dtypes.values()) and any(k.endswith('attn1.to_k.weight') and d == torch.float32 for k, d in dtypes.items())
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+@pytest.mark.parametrize('knob', ['FGDM_PAIR_LAUNCH', 'FGDM_TWIN_STREAMS'])
+def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, monkeypatch):
+    """The UNet encoder and the ControlNets are independent until the UNet's middle block (cldm.py:40,46).  Default: both walks are
+    recorded and replayed in lockstep, twin GEMM launches fused into grouped launches (FGDM_PAIR_LAUNCH, on); opt-in: the ControlNets
+    on a second stream (FGDM_TWIN_STREAMS).  Neither may change a bit of eps: same kernels, same order per net."""
+    from fgdm_amd.engine import Engine
+    x, ctx = gi.get('small/x')[:2, :, :32, :32].contiguous(), gi.get('small/ctx')[:2]
+    hints = [gi.hint(2, 256, seed=5 + k) for k in range(2)]
+    t = torch.tensor([981, 21])
+    outs = []
+    for val in ('0', '1'):
+        monkeypatch.setenv(knob, val)
+        if knob == 'FGDM_TWIN_STREAMS':
+            monkeypatch.setenv('FGDM_PAIR_LAUNCH', '0')
+        e = Engine(gi.SMALL_CFG, n_controlnets=2)           # the knobs are read at fgdm_create
+        try:
+            for k, shp in e.param_shapes().items():
+                e.load_tensor(k, synth.make_tensor(small_rename(k), shp))
+            e.finalize()
+            from fgdm_amd import _lib
+            for c, h in enumerate(hints):
+                e.set_hint(c, h)
+            outs.append(e.apply_model(x, t, ctx).cpu())
+            # a classifier-free-guidance batch cat([x] * 2) with the shared-prefix path (hints of B / 2 rows)
+            for c, h in enumerate(hints):
+                e.set_hint(c, h[:1].contiguous())
+            x2, t2 = torch.cat([x[:1], x[:1]]), torch.tensor([501, 501])
+            outs.append(e.apply_model(x2, t2, ctx, flags=_lib.FLAG_CFG_PAIRS).cpu())
+        finally:
+            e.close()
+    n = len(outs) // 2
+    for a, b in zip(outs[:n], outs[n:]):
+        assert torch.equal(a, b), float((a - b).abs().max())
