@@ -150,7 +150,7 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
         b_lds[i] = A_BYTES + idx * 1024;
     }
     const unsigned Hu = (unsigned)(a.H << up), Wu = (unsigned)(a.W << up);
-    // ... and the form the pipelined loop uses (stride 1 / 2; the launcher keeps UP2 and tensors >= 4 GB on the loop above): byte
+    // ... and the form the pipelined loop uses (the launcher keeps tensors >= 4 GB on the loop above): byte
     // offset of the slot's centre pixel in either source, and one validity bit per tap -- a piece's address is then
     // (source + tap / channel displacement: scalar) + offset, or the zero page
     unsigned a_b0[LA], a_b1[LA], a_msk[LA], b_b[LB];
@@ -167,13 +167,17 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
                     const int hw = a.Ho * a.Wo;
                     const int b = m / hw, rem = m - b * hw;
                     const int oy = (rem / a.Wo) * sy, ox = (rem - (rem / a.Wo) * a.Wo) * sy;
-                    cen = (unsigned)(b * a.H * a.W + oy * a.W + ox);
+                    // nearest-2x upsampled input (up = 1): (oy, ox) are coordinates of the upsampled image, the centre is the
+                    // source pixel (oy >> 1, ox >> 1), and a tap's source displacement depends on the parity of oy / ox:
+                    // bits 16 / 17 of the mask say "oy even" / "ox even"
+                    cen = (unsigned)(b * a.H * a.W + (oy >> up) * a.W + (ox >> up));
                     unsigned msk = 0;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const int uy = oy + t / 3 - 1, ux = ox + t % 3 - 1;
-                        if ((unsigned)uy < (unsigned)a.H && (unsigned)ux < (unsigned)a.W) msk |= 1u << t;
+                        if ((unsigned)uy < Hu && (unsigned)ux < Wu) msk |= 1u << t;
                     }
+                    if (up) msk |= ((oy & 1) ? 0u : 1u << 16) | ((ox & 1) ? 0u : 1u << 17);
                     a_msk[i] = msk;
                 }
                 a_b0[i] = (cen * (unsigned)a.C0 + (unsigned)a_off[i]) * 2u;
@@ -248,14 +252,23 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
         }
     };
     // the pipelined loop's form of a stage: (tap, cc) -> ONE scalar displacement; a piece = base + precomputed offset, or zeros
-    struct StageSc { const char* sbase; const char* wbase; unsigned lbase; bool s1; int tap; };
+    struct StageSc { const char* sbase; const char* wbase; unsigned lbase; bool s1; int tap; int dyE, dyO, dxE, dxO; };
     auto stage_scalars = [&](int kn, int tap, int cc) {
         StageSc sc;
         sc.s1 = cc >= a.C0;                                   // second source of a virtual concat
         const half_t* src = sc.s1 ? a.A1 : a.A0;
         const int Cs = sc.s1 ? a.C1 : a.C0;
         int disp = sc.s1 ? cc - a.C0 : cc;                    // halfs: channel offset (+ the tap's pixel displacement)
-        if (CONV) disp += ((tap / 3 - 1) * a.W + (tap - (tap / 3) * 3 - 1)) * Cs;
+        const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
+        sc.dyE = sc.dyO = sc.dxE = sc.dxO = 0;
+        if (CONV) {
+            if (!up) {
+                disp += (ky * a.W + kx) * Cs;
+            } else {    // source displacement in bytes by parity: even rows reach up with ky = -1, odd rows reach down with ky = +1
+                sc.dyE = ky < 0 ? -a.W * Cs * 2 : 0; sc.dyO = ky > 0 ? a.W * Cs * 2 : 0;
+                sc.dxE = kx < 0 ? -Cs * 2 : 0;       sc.dxO = kx > 0 ? Cs * 2 : 0;
+            }
+        }
         sc.sbase = (const char*)src + (ptrdiff_t)disp * 2;
         sc.wbase = (const char*)a.Wt + ((size_t)(k_begin + kn) << 6);
         sc.lbase = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (kn & 3) * STAGE_BYTES);
@@ -266,7 +279,8 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
         bool zsrc = false;
         if constexpr (ABL) zsrc = (a.debug & 8) != 0;
         if (p < LA) {
-            const unsigned off = sc.s1 ? a_b1[p] : a_b0[p];
+            unsigned off = sc.s1 ? a_b1[p] : a_b0[p];
+            if (CONV && up) off += (unsigned)(((a_msk[p] >> 16) & 1 ? sc.dyE : sc.dyO) + ((a_msk[p] >> 17) & 1 ? sc.dxE : sc.dxO));
             const char* ptr = ((a_msk[p] >> sc.tap) & 1) ? sc.sbase + off : (const char*)a.zero;
             if constexpr (ABL) { if (zsrc) ptr = (const char*)a.zero; }
             glds16_m0(ptr, sc.lbase + (wave + p * NW) * 1024);
@@ -860,11 +874,10 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if ((a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return FGDM_ERR_ARG;
     static const int pipe_default = getenv("FGDM_IGEMM_PIPE") ? atoi(getenv("FGDM_IGEMM_PIPE")) : 1;
     const int tile = cfg & 15, psel = cfg >> 4;
-    // the pipelined loop addresses with 32-bit byte offsets and stride 1 / 2 geometry: the nearest-2x-upsampled convolutions
-    // (three per evaluation) and operands of 4 GB or more stay on the phase-locked loop
+    // the pipelined loop addresses with 32-bit byte offsets: operands of 4 GB or more stay on the phase-locked loop
     const size_t px = a.mode == IG_LINEAR ? (size_t)a.M : (size_t)a.B * a.H * a.W;
     const bool small = px * (size_t)std::max(a.C0, a.C1) * 2 < (1ull << 32) && (size_t)(a.N + 320) * a.K * 2 < (1ull << 32);
-    const bool pipe = (psel == 0 ? pipe_default != 0 : psel == 2) && a.mode != IG_CONV3_UP2 && small;
+    const bool pipe = (psel == 0 ? pipe_default != 0 : psel == 2) && small;
     const int bn = (tile == 1 || tile == 4) ? 256 : tile == 6 ? 128 : tile == 7 ? 160 : 320;
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
     if (a.act == ACT_GEGLU && bn != 256) return FGDM_ERR_ARG;
