@@ -629,391 +629,6 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const half_t* __restrict__
     }
 }
 
-// =====================================================================================================================
-// Software-pipelined kernel, d = 40 (round 3).  What tools/lab/coexec_lab.hip measured on MI355X decides the structure:
-//   * a wave that streams MFMAs back to back leaves ANOTHER wave of its SIMD ~2.4 vector instructions per 32-cycle MFMA (the
-//     older wave owns the issue port): the ping-pong kernel's softmax phase takes ~900 cycles next to its partner's 448-cycle
-//     MFMA phase, which is exactly the ~960 cycles per wave-tile both kernels above run at;
-//   * the SAME wave's vector instructions placed behind each of its MFMAs do hide: MFMA + 2 v_exp_f32 + 3 others = 40 cycles.
-// So a wave overlaps, per 64-key tile k, everything else with its 14 MFMAs -- 6 of S(k+1) = K(k+1) Q^T, then 8 of
-// O^T += V^T(k-1) P^T(k-1) -- as fillers behind them (<= 2 v_exp_f32 + 3 plain vector instructions + one LDS access per gap):
-//   all gaps: exp2 of S(k) two at a time, the packs one gap behind;  gaps 0..5: the V^T(k-1) fragment reads;
-//   gaps 6..13: the row maximum of S(k+1) (its offset is decided one iteration ahead), the K(k+2) fragment reads (used by the
-//   NEXT iteration's first MFMAs: nothing waits on LDS behind the barrier), the LDS writes of the staged K(k+3) / V^T(k) chunk.
-// K tile j and V^T tile j live in LDS buffer j & 1; staged chunks travel two iterations in registers.  One barrier per tile;
-// eight waves (256 queries) per workgroup, 32 queries per wave.
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(const half_t* __restrict__ Q, int ldq,
-                                                      const half_t* __restrict__ K, int ldk,
-                                                      const half_t* __restrict__ Vt, int ldvt,
-                                                      half_t* __restrict__ O, int ldo,
-                                                      int H, int T, int Tk, float sl2e) {
-    constexpr int DP = (D + 15) / 16 * 16, NKS = DP / 16, DT = (D + 31) / 32;
-    static_assert(D == 40 && DT == 2 && NKS == 3, "needs the spare O^T row and the spare contraction slot: d = 40");
-    constexpr int PS = D / 16, PH = (D % 16) / 8;
-    constexpr int KS = DP * 2 + 16, VS = 64 * 2 + 8, DC = D / 8;
-    constexpr int NT = NW * 64;     // NW = 4: two independent workgroups per CU, so SIMD partners are NOT in lockstep
-    constexpr int KCH = (64 * DC + NT - 1) / NT, VCH = (D * 8 + NT - 1) / NT;
-    constexpr int KBYTES = 64 * KS, VBYTES = DT * 32 * VS;
-    __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lq = lane & 31, lh = lane >> 5;
-    const int nqb = (T + NW * 32 - 1) / (NW * 32);
-    const int nb = gridDim.x;
-    int logical;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, qd = nb >> 3, r = nb & 7;
-        logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
-    }
-    const int qblk = logical % nqb, bh = logical / nqb;
-    const int b = bh / H, head = bh - b * H;
-    const int q = qblk * (NW * 32) + wave * 32 + lq;
-    const int nt = (Tk + 63) / 64;
-
-    for (int buf = 0; buf < 2; ++buf) {     // pad regions, written once: K[key][40] = 1, K[key][41..47] = 0; V^T row 40 = ones, 41..63 = 0
-        char* Ksb = smem + buf * (KBYTES + VBYTES);
-        char* Vsb = Ksb + KBYTES;
-        for (int i = tid; i < 64 * (DP - D) / 8; i += NT) {
-            const int key = i / ((DP - D) / 8), c = i % ((DP - D) / 8);
-            h8 pad = (h8)(half_t)0;
-            if (c == 0) pad[0] = (half_t)1;
-            *(h8*)(Ksb + key * KS + (D + c * 8) * 2) = pad;
-        }
-        for (int i = tid; i < (DT * 32 - D) * 16; i += NT) {
-            const int r = D + i / 16, c = i % 16;
-            *(h4*)(Vsb + r * VS + c * 8) = (r == D) ? (h4)(half_t)1 : (h4)(half_t)0;
-        }
-    }
-    h8 qf[NKS];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-        const int c = 16 * s + 8 * lh;
-        qf[s] = (h8)(half_t)0;
-        if (c < D && q < T) qf[s] = *(const h8*)(Q + ((size_t)b * T + q) * ldq + head * D + c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[s][j] = (half_t)((float)qf[s][j] * sl2e);
-    }
-    f32x16 oacc[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = 0.f;
-
-    const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
-    const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // K / V^T chunks (16 bytes each) of a tile per thread: 320 of each over NT threads; loop-invariant offsets
-    int k_key[KCH], k_goff[KCH], k_loff[KCH], v_goff[VCH], v_loff[VCH];
-    bool k_on[KCH], v_on[VCH];
-#pragma unroll
-    for (int u = 0; u < KCH; ++u) {
-        const int i = tid + u * NT;
-        k_key[u] = i / DC; const int c = i - k_key[u] * DC;
-        k_goff[u] = k_key[u] * ldk + c * 8; k_loff[u] = k_key[u] * KS + c * 16;
-        k_on[u] = (u * NW + wave_u) * 64 < 64 * DC;      // wave-uniform (64 * DC and D * 8 are multiples of 64)
-    }
-#pragma unroll
-    for (int u = 0; u < VCH; ++u) {
-        const int i = tid + u * NT;
-        v_goff[u] = (i >> 3) * ldvt + (i & 7) * 8; v_loff[u] = (i >> 3) * VS + (i & 7) * 16;
-        v_on[u] = (u * NW + wave_u) * 64 < D * 8;
-    }
-    h8 kreg[KCH], vreg[VCH];
-    auto load_k = [&](int kt) {
-        if (kt >= nt) return;
-        const int k0 = kt * 64;
-#pragma unroll
-        for (int u = 0; u < KCH; ++u)
-            if (k_on[u]) {
-                int off = k_goff[u];
-                if (k0 + 64 > Tk) off += (min(k_key[u], Tk - 1 - k0) - k_key[u]) * ldk;     // rows past Tk: the last valid row (masked below)
-                kreg[u] = *(const h8*)(Kb + (size_t)k0 * ldk + off);
-            }
-    };
-    auto load_v = [&](int vt) {
-        if (vt >= nt) return;
-#pragma unroll
-        for (int u = 0; u < VCH; ++u)
-            if (v_on[u]) vreg[u] = *(const h8*)(Vb + vt * 64 + v_goff[u]);
-    };
-    auto store_k = [&](int kt) {
-        if (kt >= nt) return;
-#pragma unroll
-        for (int u = 0; u < KCH; ++u)
-            if (k_on[u]) *(h8*)(smem + (kt & 1) * (KBYTES + VBYTES) + k_loff[u]) = kreg[u];
-    };
-    auto store_v = [&](int vt) {
-        if (vt >= nt) return;
-#pragma unroll
-        for (int u = 0; u < VCH; ++u)
-            if (v_on[u]) {
-                char* dst = smem + (vt & 1) * (KBYTES + VBYTES) + KBYTES + v_loff[u];
-                const h8 v = vreg[u];
-                const h4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-                *(h4*)dst = lo;
-                *(h4*)(dst + 8) = hi;
-            }
-    };
-    const int kfrag = lq * KS + 8 * lh * 2, vfrag = lq * VS + 4 * lh * 2;
-    auto exp_inplace = [&](float& x) { asm volatile("v_exp_f32 %0, %0" : "+v"(x)); };
-    // two probabilities -> one dword of the P^T operand; volatile asm for the same reason as the exponentials: as plain casts the
-    // optimiser sinks all sixteen of them to the first use of the operand, in front of the next iteration's MFMAs
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    auto pack2 = [&](h8& dst, int pair, float a, float b) {
-        unsigned w;
-        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
-        u32x4 d = __builtin_bit_cast(u32x4, dst);
-        d[pair] = w;
-        dst = __builtin_bit_cast(h8, d);
-    };
-    // maximum over the two lane halves of a query: v_permlane32_swap.  Inline asm: handed the SAME value twice, hipcc folds the
-    // builtin's two results into one and the maximum disappears (seen in the ISA; it cost this kernel its extreme-logit cases)
-    auto xhalf_max = [&](float v) {
-        float lo = v, hi = v;
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-        return fmaxf(lo, hi);
-    };
-#ifdef ATT_DBG_STAMPS
-    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
-#define STAMP(i) { const long long _t = __builtin_amdgcn_s_memtime(); st_acc[i] += _t - st_last; st_last = _t; }
-#else
-#define STAMP(i)
-#endif
-    h8 kf[2][NKS];                 // K(k+1) fragments on entry of iteration k; K(k+2) on exit
-
-    // ---- one iteration.  On entry: sc = S(k) relative to m_run, every score <= ATT_THR; pin = P(k-1); kf = K(k+1) fragments.
-    // HAS_PV: tile k-1 exists; HAS_QK: tile k+1 exists.  ODD: parity of k (staging sets: written = ODD, loaded = 1 - ODD).
-    auto iter = [&](auto has_pv, auto has_qk, auto oddc, int k, f32x16 (&sc)[2], f32x16 (&sn)[2], h8 (&pin)[2][2], h8 (&pout)[2][2]) {
-        constexpr bool HAS_PV = decltype(has_pv)::value, HAS_QK = decltype(has_qk)::value;
-        constexpr int ODD = decltype(oddc)::value;
-#ifdef ATT_DBG_STAMPS
-        long long st_last = __builtin_amdgcn_s_memtime();
-#endif
-        __syncthreads();
-        STAMP(0)
-        load_k(k + 3); load_v(k);           // written to LDS in this iteration's last gaps
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(1)
-        h4 v0f[2][2][DT], v1f[2][2][DT];
-        const char* Vs = smem + ((k - 1) & 1) * (KBYTES + VBYTES) + KBYTES;
-        const char* Kn = smem + (k & 1) * (KBYTES + VBYTES);          // K(k+2): same parity as k
-        float mx0 = -INFINITY, mx1 = -INFINITY;
-        auto fillers = [&](int g) {
-            if (2 * g < 32) {
-                float x = sc[(2 * g) >> 4][(2 * g) & 15]; exp_inplace(x); sc[(2 * g) >> 4][(2 * g) & 15] = x;
-                float y = sc[(2 * g + 1) >> 4][(2 * g + 1) & 15]; exp_inplace(y); sc[(2 * g + 1) >> 4][(2 * g + 1) & 15] = y;
-            }
-            if (g >= 1 && g - 1 < 16) {
-                const int pr = g - 1;                                       // pair pr = elements 2 pr, 2 pr + 1 of S(k)
-                pack2(pout[pr >> 3][(pr >> 2) & 1], pr & 3, sc[pr >> 3][(2 * pr) & 15], sc[pr >> 3][(2 * pr + 1) & 15]);
-            }
-            if (HAS_PV && g < 6) {                                          // 8 (sub, s, t) fragment pairs over 6 gaps: 2, 2, 1, 1, 1, 1
-                const int f0 = g < 2 ? 2 * g : 2 + g, fn = g < 2 ? 2 : 1;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (u < fn) {
-                        const int f = f0 + u, sub = f >> 2, sx = (f >> 1) & 1, t = f & 1;
-                        const char* vp = Vs + vfrag + t * 32 * VS + (sub * 32 + 16 * sx) * 2;
-                        v0f[sub][sx][t] = *(const h4*)vp;
-                        v1f[sub][sx][t] = *(const h4*)(vp + 16);
-                    }
-            }
-            if (HAS_QK && g >= 6 && g < 14) {                               // row maximum of S(k+1): sn[0] in gaps 6..9, sn[1] in 10..13
-                const int h = (g - 6) >> 2, j = ((g - 6) & 3) * 4;
-                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx0) : "v"(sn[h][j]), "v"(sn[h][j + 1]));
-                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx1) : "v"(sn[h][j + 2]), "v"(sn[h][j + 3]));
-            }
-            if (HAS_QK && g >= 6 && g < 12) {                               // the six K(k+2) fragments, one per gap (kf is free by now)
-                const int f = g - 6, fs = f / NKS, fk = f % NKS;
-                kf[fs][fk] = *(const h8*)(Kn + kfrag + fs * 32 * KS + 16 * fk * 2);
-            }
-            if (g == 12) store_k(k + 3);      // buffer of K(k+1), whose fragments everybody read in iteration k-1
-            if (g == 13) store_v(k);          // buffer of V^T(k-2)
-        };
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int g = 0;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                // (the first k-step takes C = 0 as an inline constant: no v_mov per accumulator register)
-                if constexpr (HAS_QK) sn[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sub][s], qf[s], s == 0 ? zero16 : sn[sub], 0, 0, 0);
-                fillers(g);
-                __builtin_amdgcn_sched_barrier(0);
-                ++g;
-            }
-        STAMP(2)
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    if constexpr (HAS_PV) {
-                        const h4 v0 = v0f[sub][s][t], v1 = v1f[sub][s][t];
-                        const h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pin[sub][s], oacc[t], 0, 0, 0);
-                    }
-                    fillers(g);
-                    __builtin_amdgcn_sched_barrier(0);
-                    ++g;
-                }
-        STAMP(3)
-        fillers(14); fillers(15); fillers(16);      // what is left: elements 28..31, pairs 13..15
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (HAS_QK) {
-            // ---- the decision for tile k + 1.  Its scores were taken against m_run (the Q slot), as everything else in flight.
-            float mx = fmaxf(mx0, mx1);
-            if ((k + 2) * 64 > Tk) {                // tile k + 1 is ragged (only the last one can be): keys >= Tk get -inf
-                mx = -INFINITY;
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = (k + 1) * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (key >= Tk) sn[sub][r] = -INFINITY;
-                        mx = fmaxf(mx, sn[sub][r]);
-                    }
-            }
-            mx = xhalf_max(mx);
-            if (!__all(mx <= ATT_THR)) {            // wave-uniform, rare after the first tiles: raise the offset
-                const float m_hat = (float)(half_t)(m_run + fmaxf(mx, 0.f));     // exactly what Q[q][40] can hold
-                const float delta = m_run - m_hat;
-                const float alpha = __builtin_amdgcn_exp2f(delta);
-                m_run = m_hat;
-                // everything expressed against the old offset: O (P(k-1) has just joined it), P(k), S(k+1)
-#pragma unroll
-                for (int t = 0; t < DT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-                const half_t ah = (half_t)alpha;
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pout[sub][s][j] = pout[sub][s][j] * ah;
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sn[sub][r] += delta;
-                if (lh == PH) qf[PS][0] = (half_t)(-m_hat);
-            }
-        }
-        STAMP(4)
-    };
-
-    // ---- prologue: K(0), K(1) into their buffers; S(0) and its offset; K(1) fragments; then K(2) over K(0)
-    constexpr std::integral_constant<int, 0> set0{};
-    constexpr std::integral_constant<int, 1> set1{};
-    load_k(0); store_k(0);
-    load_k(1); store_k(1);
-    __syncthreads();
-    f32x16 sA[2], sB[2];           // S(k): sA for even k, sB for odd k
-    h8 pA[2][2], pB[2][2];         // P(k): pA for even k, pB for odd k
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { pA[sub][s] = (h8)(half_t)0; pB[sub][s] = (h8)(half_t)0; }
-    {
-        const char* Ks = smem;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sA[sub][r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < NKS; ++s)
-                sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Ks + kfrag + sub * 32 * KS + 16 * s * 2), qf[s], sA[sub], 0, 0, 0);
-        }
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) kf[sub][s] = *(const h8*)(smem + (KBYTES + VBYTES) + kfrag + sub * 32 * KS + 16 * s * 2);
-        if (64 > Tk) {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) sA[sub][r] = -INFINITY;
-        }
-        float mx = fmaxf(sA[0][0], sA[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sA[0][r]), sA[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_hat = (float)(half_t)mx;      // first tile: the offset is its row maximum (m_run was 0, the Q slot too)
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sA[sub][r] -= m_hat;
-        m_run = m_hat;
-        if (lh == PH) qf[PS][0] = (half_t)(-m_hat);
-    }
-    __syncthreads();               // everybody has read K(0) and the K(1) fragments: K(2) may replace K(0)
-    load_k(2); store_k(2);
-    constexpr std::true_type yes{};
-    constexpr std::false_type no{};
-    if (nt == 1) {
-        iter(no, no, set0, 0, sA, sB, pB, pA);
-    } else {
-        iter(no, yes, set0, 0, sA, sB, pB, pA);
-        int k = 1;
-        for (; k + 2 < nt; k += 2) {                    // middle iterations in pairs: the register roles are static in the loop
-            iter(yes, yes, set1, k, sB, sA, pA, pB);
-            iter(yes, yes, set0, k + 1, sA, sB, pB, pA);
-        }
-        if (k + 1 < nt) {
-            iter(yes, yes, set1, k, sB, sA, pA, pB);
-            iter(yes, no, set0, k + 1, sA, sB, pB, pA);
-        } else {
-            iter(yes, no, set1, k, sB, sA, pA, pB);
-        }
-    }
-    __syncthreads();
-    {   // O^T += V^T(nt-1) P^T(nt-1)
-        const char* Vs = smem + ((nt - 1) & 1) * (KBYTES + VBYTES) + KBYTES;
-        h8 (&pl)[2][2] = ((nt - 1) & 1) ? pB : pA;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    const char* vp = Vs + vfrag + t * 32 * VS + (sub * 32 + 16 * s) * 2;
-                    const h4 v0 = *(const h4*)vp, v1 = *(const h4*)(vp + 16);
-                    const h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl[sub][s], oacc[t], 0, 0, 0);
-                }
-    }
-    constexpr int rr = D % 32;
-    constexpr int reg = (rr & 3) + 4 * (rr >> 3);
-    constexpr int owner_half = (rr >> 2) & 1;
-    const float mine = oacc[D / 32][reg];
-    const float other = __shfl_xor(mine, 32);
-    const float inv = 1.0f / ((lh == owner_half) ? mine : other);
-#ifdef ATT_DBG_STAMPS
-    if (lane == 0 && blockIdx.x % 97 == 0) {
-        for (int i = 0; i < 5; ++i) printf("wg %d wave %d phase %d cycles/tile %lld\n", (int)blockIdx.x, wave, i, st_acc[i] / nt);
-    }
-#endif
-    if (q < T) {
-        half_t* op = O + ((size_t)b * T + q) * ldo + head * D;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = t * 32 + 8 * g + 4 * lh;
-                if (dd < D) {
-                    h4 pk = {(half_t)(oacc[t][4 * g] * inv), (half_t)(oacc[t][4 * g + 1] * inv),
-                             (half_t)(oacc[t][4 * g + 2] * inv), (half_t)(oacc[t][4 * g + 3] * inv)};
-                    *(h4*)(op + dd) = pk;
-                }
-            }
-    }
-}
-#undef STAMP
-
 int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* Vt, int ldvt, half_t* O,
                      int ldo, int B, int H, int T, int Tk, int d, int q_prescaled, hipStream_t s) {
     if (B <= 0 || H <= 0 || T <= 0 || Tk <= 0) return FGDM_ERR_ARG;
@@ -1023,13 +638,6 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
     const float sl2e = q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)d);
     // long self-attention: the eight-wave ping-pong kernel (256 queries per workgroup); FGDM_ATTN_PP=0 switches it off (A/B)
     static const bool pp_on = !(getenv("FGDM_ATTN_PP") && atoi(getenv("FGDM_ATTN_PP")) == 0);
-    // d = 40: the software-pipelined kernel; FGDM_ATTN_SP = 8: eight waves (256 queries) per workgroup, 4: four waves, two workgroups per CU
-    static const int sp_nw = getenv("FGDM_ATTN_SP") ? atoi(getenv("FGDM_ATTN_SP")) : 0;
-    if (sp_nw && T >= 256 && Tk >= 256 && d == 40) {
-        if (sp_nw == 4) FGDM_LAUNCH((attn_sp_kernel<40, 4>), dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
-        else FGDM_LAUNCH((attn_sp_kernel<40, 8>), dim3(((T + 255) / 256) * H * B), dim3(512), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
-        return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
-    }
     if (pp_on && T >= 256 && Tk >= 256 && (d == 40 || d == 80)) {
         const dim3 grid2(((T + 255) / 256) * H * B), block2(512);
         if (d == 40) FGDM_LAUNCH(attn_pp_kernel<40>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);

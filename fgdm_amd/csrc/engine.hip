@@ -2548,9 +2548,13 @@ int fgdm_bench_attention(int B, int heads, int T, int Tk, int d, int iters, floa
     unsigned st = 4242u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 9) & 0xffff) / 32768.0f - 1.0f; };
     std::vector<half_t> hq((size_t)B * T * C), hk((size_t)B * Tk * C), hv((size_t)B * C * Tkp, (half_t)0);
-    for (auto& v : hq) v = (half_t)(rnd() * 1.5f);
-    for (auto& v : hk) v = (half_t)(rnd() * 1.5f);
-    for (size_t r = 0; r < (size_t)B * C; ++r) for (int t = 0; t < Tk; ++t) hv[r * Tkp + t] = (half_t)rnd();
+    // FGDM_BENCH_DATA_SCALE (default 1) scales the operands: 0 gives the all-zero run that separates data-dependent
+    // power draw from instruction issue.
+    const char* dsv = getenv("FGDM_BENCH_DATA_SCALE");
+    const float ds = dsv ? (float)atof(dsv) : 1.0f;
+    for (auto& v : hq) v = (half_t)(rnd() * 1.5f * ds);
+    for (auto& v : hk) v = (half_t)(rnd() * 1.5f * ds);
+    for (size_t r = 0; r < (size_t)B * C; ++r) for (int t = 0; t < Tk; ++t) hv[r * Tkp + t] = (half_t)(rnd() * ds);
     TmpDev tmp;
     half_t* o = nullptr;
     if (hipMalloc(&o, (size_t)B * T * C * sizeof(half_t)) != hipSuccess) return FGDM_ERR_NOMEM;
