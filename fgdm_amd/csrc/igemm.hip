@@ -374,7 +374,9 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     if (a.out2 && (a.act == ACT_GEGLU || a.splitk > 1 || a.stats_out || a.split_n <= 0 || a.split_n >= a.N || (a.split_n % 640))) return FGDM_ERR_ARG;
     if (a.splitk > 1) {        // split-K plan made by the caller (igemm_splitk_factor): 128x320 tiles + reduction pass
         if (!a.ws || a.ln_stats) return FGDM_ERR_ARG;
-        const int rc = igemm2_launch(a, 2, s);
+        // 256 x 320 tiles once they fill the chip (eight-way splits at B = 32), else 128 x 320: the tile changes no sum's order
+        const bool fat = a.splitk >= 8 && (long)((a.M + 255) / 256) * (a.N / 320) * a.splitk >= 192 && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31);
+        const int rc = igemm2_launch(a, fat ? 0 : 2, s);
         return rc == FGDM_OK ? igemm_splitk_reduce(a, s) : rc;
     }
     int force = pick_force(a);

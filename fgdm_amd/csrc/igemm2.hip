@@ -856,7 +856,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a) {
 int igemm_splitk_factor(const IgemmArgs& a) {
     if (a.force_cfg || a.act == ACT_GEGLU || a.out_kind != OUT_F16 || a.N % 320 || (a.K & 31)) return 1;
     const int nk = a.K >> 5;
-    return (a.rows_per_sample <= 64 && nk >= 96) ? 4 : 1;
+    if (a.rows_per_sample > 64 || nk < 96) return 1;
+    // the 3x3 convolutions of that level (K >= 11520) split eight ways: at B = 32 that is what lets them run on 256 x 320 tiles
+    // (igemm_launch), two thirds of the L2 -> LDS bytes of the 128-row tiles (same box, B = 32: 1280->1280 88 -> 84 us,
+    // 2560->1280 164 -> 137 us; the K = 5120 linear loses with either change and stays at four)
+    static const bool fat = !(getenv("FGDM_SPLITK_FAT") && atoi(getenv("FGDM_SPLITK_FAT")) == 0);          // A/B knob
+    return (fat && nk >= 360) ? 8 : 4;
 }
 int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
     const size_t total4 = (size_t)a.M * a.N / 4;
@@ -882,7 +887,10 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if (a.N % bn) return FGDM_ERR_ARG;          // weight rows beyond N are not padded to this tile
     if (a.act == ACT_GEGLU && bn != 256) return FGDM_ERR_ARG;
     if (a.splitk > 1) {
-        if (tile != 2 || a.ln_stats) return FGDM_ERR_ARG;
+        if ((tile != 2 && tile != 0) || a.ln_stats) return FGDM_ERR_ARG;
+        if (tile == 0 && pipe)       // (the phase-locked loop has no 256 x 320 split-K instantiation: 128 x 320 below)
+            return a.mode == IG_LINEAR ? launch2<256, 320, 4, 2, 4, false, false, true, 16, false, false, 1>(a, s)
+                                       : launch2<256, 320, 4, 2, 4, true, false, true, 16, false, false, 1>(a, s);
         if (pipe)
             return a.mode == IG_LINEAR ? launch2<128, 320, 4, 2, 4, false, false, true, 16, false, false, 1>(a, s)
                                        : launch2<128, 320, 4, 2, 4, true, false, true, 16, false, false, 1>(a, s);

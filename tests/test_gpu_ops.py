@@ -62,6 +62,8 @@ CONV_CASES = [
     (2, 7, 5, 64, 0, 96, 3, 2, 0, 0, 'odd sizes'),
     (3, 8, 8, 640, 0, 320, 3, 1, 0, 1, 'split-K (8x8, K=5760) silu + rowvec + resid'),
     (2, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 'split-K decoder concat (8x8, K=23040)'),
+    (24, 8, 8, 1280, 0, 1280, 3, 1, 0, 0, 'split-K x8 on 256x320 tiles (8x8, K=11520, B=24) rowvec + resid'),
+    (25, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 'split-K x8 on 256x320 tiles, decoder concat, M tail (B=25)'),
 ]
 
 
