@@ -375,7 +375,7 @@ int igemm_launch(const IgemmArgs& a, hipStream_t s) {
     if (a.splitk > 1) {        // split-K plan made by the caller (igemm_splitk_factor): 128x320 tiles + reduction pass
         if (!a.ws || a.ln_stats) return FGDM_ERR_ARG;
         // 256 x 320 tiles once they fill the chip (eight-way splits at B = 32), else 128 x 320: the tile changes no sum's order
-        const bool fat = a.splitk >= 8 && (long)((a.M + 255) / 256) * (a.N / 320) * a.splitk >= 192 && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31);
+        const bool fat = (long)((a.M + 255) / 256) * (a.N / 320) * a.splitk >= 192 && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31);
         const int rc = igemm2_launch(a, fat ? 0 : 2, s);
         return rc == FGDM_OK ? igemm_splitk_reduce(a, s) : rc;
     }
