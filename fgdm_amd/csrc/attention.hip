@@ -23,6 +23,7 @@
 // (variants that were measured and rejected, and what bounds these kernels: DESIGN.md section 4.2 / 4.3)
 #include "common.h"
 #include <type_traits>
+#include <algorithm>
 #include <stdlib.h>
 
 #define ATT_THR 8.0f
@@ -59,8 +60,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
         const int bid = blockIdx.x, xcd = bid & 7, qd = nb >> 3, r = nb & 7;
         logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
     }
-    const int qblk = logical % nqb, bh = logical / nqb;
-    const int b = bh / H, head = bh - b * H;
+    // Cross-attention (Tk <= 128: K / Vt of a head are 6-25 KB, nothing to share) is bound by its Q reads and O writes, and a
+    // head's slice of a token row is 2 D bytes of a 2 H D-byte row: there the HEAD runs fastest, so the H workgroups that touch
+    // the same 128 rows are neighbours on one XCD and every 128-byte line of Q and O crosses the fabric once instead of once per
+    // head that owns a piece of it (T = 4096, d = 40: 80 -> see DESIGN.md section 4.3)
+    int qblk, b, head;
+    if (Tk <= 128) {
+        head = logical % H;
+        const int rest = logical / H;
+        qblk = rest % nqb; b = rest / nqb;
+    } else {
+        qblk = logical % nqb;
+        const int bh = logical / nqb;
+        b = bh / H; head = bh - b * H;
+    }
     const int q = qblk * 128 + wave * 32 + lq;
 
     // pad regions of both buffers, written once: K pad columns [D, DP) = 0; Vt pad rows [D, DT*32) = 0, row D = 1
@@ -332,6 +345,251 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     }
 }
 
+
+// =====================================================================================================================
+// Cross-attention (64 < Tk <= 96: the 77 text tokens).  The kernel above gives every 128 queries their own workgroup, which
+// stages K / V^T tile by tile behind barriers: with two tiles of keys that is three dependent memory round trips and two barriers
+// for 50 MFMAs -- latency-bound at 2.2 TB/s of Q + O traffic (72 us at T = 4096, d = 40).  Here a workgroup stages ALL keys of its
+// (batch, head) once (K [96][DP], V^T [d][96] with the ones row), passes ONE barrier, and then each of its four waves walks CPW
+// chunks of 32 queries on its own: S^T = K Q^T for the three 32-key sub-tiles in one go, a plain (single-pass) softmax, O^T = V^T P^T;
+// the next chunk's Q rows are requested before the current chunk is computed.  Heads run fastest over workgroups (see above).
+template <int D>
+__global__ __launch_bounds__(256) void attn_cross_kernel(const half_t* __restrict__ Q, int ldq,
+                                                         const half_t* __restrict__ K, int ldk,
+                                                         const half_t* __restrict__ Vt, int ldvt,
+                                                         half_t* __restrict__ O, int ldo,
+                                                         int H, int T, int Tk, float sl2e, int cpw) {
+    constexpr int NS = 3, KEYS = NS * 32;
+    constexpr int DP = (D + 15) / 16 * 16, NKS = DP / 16, DT = (D + 31) / 32;
+    constexpr bool ONES = (DT * 32 > D);
+    constexpr bool FOLD = (DP > D) && (D % 8 == 0);      // same Q scaling rule as attn_kernel (the spare slot itself stays 0 here)
+    constexpr int KS = DP * 2 + 16;            // K row stride (bytes): odd multiple of 16
+    constexpr int VS = KEYS * 2 + 72;          // V^T row stride: 66 dwords = 2 mod 32 -> b64 reads conflict-free like the 34 above
+    constexpr int DC = D / 8;
+    // Q rows enter and O rows leave through a wave-private [32][D] LDS tile, so that global memory sees 16-byte pieces of whole
+    // 2 D-byte row slices (a lane per query row means 64 different lines per instruction, 8 bytes each on the way out)
+    constexpr bool RELAY = D <= 80;
+    constexpr int RS = D * 2 + 8;              // 22 / 42 dwords per row: 8-byte accesses of 16 consecutive rows hit 16 banks
+    constexpr int PCS = 32 * (D / 8), KP = (PCS + 63) / 64;      // 16-byte pieces of a 32-row chunk; per lane
+    __shared__ __attribute__((aligned(16))) char smem[KEYS * KS + DT * 32 * VS + (RELAY ? 4 * 32 * RS : 0)];
+    char* Ks = smem;
+    char* Vs = smem + KEYS * KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int qpw = 128 * cpw;                               // queries per workgroup
+    const int ncb = (T + qpw - 1) / qpw;
+    const int nb = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qd = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
+    }
+    const int head = logical % H, rest = logical / H;
+    const int cblk = rest % ncb, b = rest / ncb;
+
+    const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
+    const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
+    // ---- stage K (rows past Tk repeat the last valid one: their scores are masked) and V^T (rows are padded to 64-key multiples):
+    // every global load of the workgroup is issued before the first LDS store -- ONE memory round trip (as loops of load / store
+    // pairs the staging was 5-6 dependent round trips, most of a workgroup's life)
+    constexpr int KPC = KEYS * (DP / 8), VPC = DT * 32 * (KEYS / 8);
+    constexpr int KPT = (KPC + 255) / 256, VPT = (VPC + 255) / 256;
+    h8 kst[KPT], vst[VPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = tid + 256 * u, key = i / (DP / 8), c = i - key * (DP / 8);
+        kst[u] = (h8)(half_t)0;
+        if (i < KPC && c < DC) kst[u] = *(const h8*)(Kb + (size_t)min(key, Tk - 1) * ldk + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int i = tid + 256 * u, r = i / (KEYS / 8), c = i - r * (KEYS / 8);
+        vst[u] = (r == D) ? (h8)(half_t)1 : (h8)(half_t)0;
+        if (i < VPC && r < D) vst[u] = *(const h8*)(Vb + (size_t)r * ldvt + c * 8);
+    }
+    char* scr = smem + KEYS * KS + DT * 32 * VS + (threadIdx.x >> 6) * 32 * RS;      // this wave's tile
+    // the chunk's Q rows: per-lane fragments straight from global memory, or (RELAY) 16-byte pieces in row order
+    constexpr int NQ = RELAY ? KP : NKS;
+    auto load_q = [&](int q0, h8 (&qr)[NQ]) {      // q0: first query of the chunk (wave-uniform)
+        if constexpr (RELAY) {
+#pragma unroll
+            for (int u = 0; u < KP; ++u) {
+                const int c = lane + 64 * u, row = c / (D / 8), ck = c - row * (D / 8);
+                qr[u] = (h8)(half_t)0;
+                if (c < PCS && q0 + row < T) qr[u] = *(const h8*)(Q + ((size_t)b * T + q0 + row) * ldq + head * D + ck * 8);
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < NKS; ++s2) {
+                const int c = 16 * s2 + 8 * lh;
+                qr[s2] = (h8)(half_t)0;
+                if (c < D && q0 + lq < T) qr[s2] = *(const h8*)(Q + ((size_t)b * T + q0 + lq) * ldq + head * D + c);
+            }
+        }
+    };
+    const int q_first = cblk * qpw + wave * 32;              // chunk i of this wave: queries q_first + i * 128 + [0, 32)
+    h8 qn[NQ];
+    load_q(q_first, qn);
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = tid + 256 * u, key = i / (DP / 8), c = i - key * (DP / 8);
+        if (i < KPC) *(h8*)(Ks + key * KS + c * 16) = kst[u];
+    }
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int i = tid + 256 * u, r = i / (KEYS / 8), c = i - r * (KEYS / 8);
+        if (i < VPC) {
+            const h8 v = vst[u];
+            const h4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+            *(h4*)(Vs + r * VS + c * 16) = lo;
+            *(h4*)(Vs + r * VS + c * 16 + 8) = hi;
+        }
+    }
+    __syncthreads();
+
+    const int kfrag = lq * KS + 8 * lh * 2, vfrag = lq * VS + 4 * lh * 2;
+    for (int i = 0; i < cpw; ++i) {
+        const int q0 = __builtin_amdgcn_readfirstlane(q_first + i * 128);
+        if (q0 >= T) break;                                  // wave-uniform: this chunk starts past the end
+        const int q = q0 + lq;
+        h8 qf[NKS];
+        if constexpr (RELAY) {
+#pragma unroll
+            for (int u = 0; u < KP; ++u) {
+                const int c = lane + 64 * u, row = c / (D / 8), ck = c - row * (D / 8);
+                if (c < PCS) {
+                    const h4 lo = {qn[u][0], qn[u][1], qn[u][2], qn[u][3]}, hi = {qn[u][4], qn[u][5], qn[u][6], qn[u][7]};
+                    *(h4*)(scr + row * RS + ck * 16) = lo;
+                    *(h4*)(scr + row * RS + ck * 16 + 8) = hi;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < NKS; ++s2) {
+                const int c = 16 * s2 + 8 * lh;
+                qf[s2] = (h8)(half_t)0;
+                if (c < D) {
+                    const h4 lo = *(const h4*)(scr + lq * RS + c * 2), hi = *(const h4*)(scr + lq * RS + c * 2 + 8);
+                    qf[s2] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments read before the tile is reused for O
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < NKS; ++s2) qf[s2] = qn[s2];
+        }
+        if (i + 1 < cpw) load_q(q0 + 128, qn);
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int s2 = 0; s2 < NKS; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[s2][j] = (half_t)((float)qf[s2][j] * sl2e);
+        }
+        // ---- S^T = K Q^T, all keys
+        f32x16 sacc[NS];
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < NKS; ++s2) {
+                const h8 kf = *(const h8*)(Ks + kfrag + sub * 32 * KS + 16 * s2 * 2);
+                sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s2], sacc[sub], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {           // only the last sub-tile can hold keys >= Tk (64 < Tk <= 96)
+            const int key = (NS - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= Tk) sacc[NS - 1][r] = -INFINITY;
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float sc = FOLD ? 1.0f : sl2e;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f((sacc[sub][r] - mx) * sc);
+                sacc[sub][r] = pv;
+                if constexpr (!ONES) psum += pv;
+            }
+        // ---- O^T = V^T P^T (row D of O^T: the sum of the fp16 probabilities)
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                h8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[sub][8 * s2 + j];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const char* vp = Vs + vfrag + t * 32 * VS + (sub * 32 + 16 * s2) * 2;
+                    const h4 v0 = *(const h4*)vp, v1 = *(const h4*)(vp + 16);
+                    const h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[t], 0, 0, 0);
+                }
+            }
+        float l_tot;
+        if constexpr (ONES) {
+            constexpr int rr = D % 32;
+            constexpr int reg = (rr & 3) + 4 * (rr >> 3);
+            constexpr int owner_half = (rr >> 2) & 1;
+            const float mine = oacc[D / 32][reg];
+            const float other = __shfl_xor(mine, 32);
+            l_tot = (lh == owner_half) ? mine : other;
+        } else {
+            l_tot = psum + __shfl_xor(psum, 32);
+        }
+        const float inv = 1.0f / l_tot;
+        if constexpr (RELAY) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dd = t * 32 + 8 * g + 4 * lh;
+                    if (dd < D) {
+                        h4 pk = {(half_t)(oacc[t][4 * g] * inv), (half_t)(oacc[t][4 * g + 1] * inv),
+                                 (half_t)(oacc[t][4 * g + 2] * inv), (half_t)(oacc[t][4 * g + 3] * inv)};
+                        *(h4*)(scr + lq * RS + dd * 2) = pk;
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < KP; ++u) {
+                const int c = lane + 64 * u, row = c / (D / 8), ck = c - row * (D / 8);
+                if (c < PCS && q0 + row < T) {
+                    const h4 lo = *(const h4*)(scr + row * RS + ck * 16), hi = *(const h4*)(scr + row * RS + ck * 16 + 8);
+                    *(h8*)(O + ((size_t)b * T + q0 + row) * ldo + head * D + ck * 8) = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile is free for the next chunk's Q
+        } else if (q < T) {
+            half_t* op = O + ((size_t)b * T + q) * ldo + head * D;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dd = t * 32 + 8 * g + 4 * lh;
+                    if (dd < D) {
+                        h4 pk = {(half_t)(oacc[t][4 * g] * inv), (half_t)(oacc[t][4 * g + 1] * inv),
+                                 (half_t)(oacc[t][4 * g + 2] * inv), (half_t)(oacc[t][4 * g + 3] * inv)};
+                        *(h4*)(op + dd) = pk;
+                    }
+                }
+        }
+    }
+}
 
 // =====================================================================================================================
 // Ping-pong variant for long self-attention (round 2).  PMC on the kernel above (T = Tk = 4096, d = 40): per SIMD the matrix
@@ -642,6 +900,19 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
         const dim3 grid2(((T + 255) / 256) * H * B), block2(512);
         if (d == 40) FGDM_LAUNCH(attn_pp_kernel<40>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
         else FGDM_LAUNCH(attn_pp_kernel<80>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+    }
+    // the text tokens: all keys staged once per workgroup, several query chunks per wave; FGDM_ATTN_CROSS=0 switches it off (A/B)
+    static const int cross = getenv("FGDM_ATTN_CROSS") ? atoi(getenv("FGDM_ATTN_CROSS")) : 4;
+    if (cross > 0 && Tk > 64 && Tk <= 96 && ldvt >= 96 && T >= 128) {
+        const int cpw = std::min(cross, T / 128);
+        const dim3 gridc(((T + 128 * cpw - 1) / (128 * cpw)) * H * B), blockc(256);
+        switch (d) {
+            case 40: FGDM_LAUNCH(attn_cross_kernel<40>, gridc, blockc, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e, cpw); break;
+            case 80: FGDM_LAUNCH(attn_cross_kernel<80>, gridc, blockc, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e, cpw); break;
+            case 160: FGDM_LAUNCH(attn_cross_kernel<160>, gridc, blockc, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e, cpw); break;
+            default: return FGDM_ERR_ARG;
+        }
         return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
     }
     const dim3 grid(((T + 127) / 128) * H * B), block(256);

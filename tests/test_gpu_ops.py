@@ -196,7 +196,11 @@ ATT_CASES = [(2, 8, 64, 64, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80),
              (2, 8, 64, 77, 40), (1, 8, 4096, 77, 40), (2, 8, 256, 77, 160), (2, 8, 1, 1, 160), (2, 8, 16, 16, 80),
              (1, 4, 200, 130, 80),
              # the half-tile boundary of the last key tile (second 32-key sub-tile skipped when it starts at or beyond Tk)
-             (1, 8, 64, 32, 40), (1, 8, 64, 33, 80), (1, 8, 128, 96, 40), (1, 8, 128, 97, 160)]
+             (1, 8, 64, 32, 40), (1, 8, 64, 33, 80), (1, 8, 128, 96, 40), (1, 8, 128, 97, 160),
+             # the text-token kernel (64 < Tk <= 96, T >= 128): every head width, ragged T (a wave's last chunk partly / wholly
+             # past the end), one and several chunks per wave, the key-count limits
+             (2, 8, 1024, 77, 80), (2, 8, 512, 77, 160), (1, 8, 700, 77, 40), (3, 8, 130, 77, 80), (1, 8, 512, 96, 40),
+             (1, 8, 640, 65, 80), (2, 4, 256, 77, 160)]
 
 
 @pytest.mark.parametrize('case', ATT_CASES, ids=[f'B{c[0]}_H{c[1]}_T{c[2]}_Tk{c[3]}_d{c[4]}' for c in ATT_CASES])
@@ -357,6 +361,7 @@ LN_CASES = [
     (200, 320, 320, 320, 0, True, 0, -2),       # small problem: 2-stage kernel + the separate row-statistics pass (same 2 slots)
     (16384, 320, 320, 640, 0, True, 1, -2),     # the same shape as case 0 forced onto the 2-stage kernel
     (4100, 640, 640, 640, 0, False, 6, 4),      # ragged M on the 128x320 tiles
+    (8192, 1280, 1280, 3840, 0, True, 0, 8),    # the 16x16 level's q|k|v width: 256x256 tiles divide the chip better (automatic)
     (2048, 1280, 1280, 1280, 0, True, 0, -8),   # the 8x8 level: 64x160 four-wave tiles (automatic), statistics from the separate pass
 ]
 

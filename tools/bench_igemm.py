@@ -24,11 +24,14 @@ SHAPES = [
     ('L2 conv 2560->1280 cat', 32, 16, 16, 1280, 1280, 1280, 3, 1, 0, 0, 0),
     ('L2 lin 1280->1280', 32, 16, 16, 1280, 0, 1280, 1, 1, 0, 0, 1),
     ('L2 geglu 1280->10240', 32, 16, 16, 1280, 0, 10240, 1, 1, 0, 3, 0),
+    ('L2 lin 1280->3840 (qkv)', 32, 16, 16, 1280, 0, 3840, 1, 1, 0, 0, 0),
+    ('L2 lin 5120->1280 (ffo)', 32, 16, 16, 5120, 0, 1280, 1, 1, 0, 0, 1),
     ('L3 conv 1280->1280', 32, 8, 8, 1280, 0, 1280, 3, 1, 0, 0, 1),
     ('L3 conv 2560->1280 cat', 32, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 0),
     ('L3 lin 1280->1280', 32, 8, 8, 1280, 0, 1280, 1, 1, 0, 0, 1),
     ('L3 lin 1280->3840 (qkv)', 32, 8, 8, 1280, 0, 3840, 1, 1, 0, 0, 0),
     ('L3 lin 5120->1280 (ffo)', 32, 8, 8, 5120, 0, 1280, 1, 1, 0, 0, 1),
+    ('L3 geglu 1280->10240', 32, 8, 8, 1280, 0, 10240, 1, 1, 0, 3, 0),
     ('L1 down s2 320->320', 32, 64, 64, 320, 0, 320, 3, 2, 0, 0, 0),
     ('L0 up 640->640', 32, 32, 32, 640, 0, 640, 3, 1, 1, 0, 0),
     # the same GEMMs as the L0 / L1 / L2 convolutions without the 3x3 gather (what the addressing and the tap re-reads cost)
