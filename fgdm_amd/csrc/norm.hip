@@ -151,13 +151,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 // reductions as the two-kernel path -> bitwise independent of the batch.
 template <int NT>   // threads per workgroup: 256 when 3+ workgroups share a CU, 512 when one 80 KB slice owns it (memory-level parallelism)
 __global__ __launch_bounds__(NT) void gn_fused_kernel(const half_t* __restrict__ x0, int C0,
-                                                        const half_t* __restrict__ x1, int C1, int HW, int NG,
+                                                        const half_t* __restrict__ x1, int C1, int B, int HW, int NG,
                                                         float eps, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu,
                                                         half_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int C = C0 + C1, cpg = C >> 5, CW = NG * cpg, OW = CW >> 3;     // slice width in channels / octets
-    const int b = blockIdx.y, c_lo = blockIdx.x * CW;
+    // the 32 / NG slices of ONE sample share an XCD (workgroup ids are dealt round-robin over the eight): see gn_reg_kernel
+    const int NS = 32 / NG, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int b = (k / NS) * 8 + xcd, c_lo = (k % NS) * CW;
+    if (b >= B) return;
     const int tid = threadIdx.x;
     half_t* tile = (half_t*)gsm;                                   // [HW][CW]
     float* red = (float*)(gsm + (size_t)HW * CW * 2);              // [PI][CW][2]
@@ -241,6 +244,104 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const half_t* __restrict__
     }
 }
 
+// Large feature maps (the 64x64 / 32x32 levels: a slice of NG whole groups of one sample is 160-330 KB, more than LDS holds): the
+// slice lives in the REGISTERS of one 1024-thread workgroup (NP 16-byte pieces per thread: 84 of the 128 registers a thread has at
+// that occupancy), so x is read once instead of twice and the second launch disappears, exactly as in the kernel above; only the
+// per-channel partial sums go through LDS.  One workgroup per CU; all of them load (every piece requested before the first use), then
+// reduce, then store: HBM sees a pure read phase and a pure write phase.  Same fixed-order reductions -> independent of the batch.
+template <int NP>
+__global__ __launch_bounds__(1024) void gn_reg_kernel(const half_t* __restrict__ x0, int C0,
+                                                      const half_t* __restrict__ x1, int C1, int B, int HW, int NG,
+                                                      float eps, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int silu,
+                                                      half_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int C = C0 + C1, cpg = C >> 5, CW = NG * cpg, OW = CW >> 3;
+    // a slice is 2 CW bytes of every 2 C-byte pixel row: the 32 / NG slices of ONE sample go to one XCD (workgroup ids are dealt
+    // round-robin over the eight), neighbours in time, so its L2 fetches every 128-byte line of x once instead of once per slice
+    // that owns a piece of it (without this the 64x64 level read 1.6x its bytes and lost to the two-kernel path)
+    const int NS = 32 / NG, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int b = (k / NS) * 8 + xcd, c_lo = (k % NS) * CW;
+    if (b >= B) return;
+    const int tid = threadIdx.x;
+    const int PI = 1024 / OW;                                      // pixel lanes; NP * PI >= HW (host)
+    float* red = (float*)gsm;                                      // [PI][CW][2]
+    float* stats = red + (size_t)PI * CW * 2;                      // [NG][2]
+    float* scale = stats + 8;                                      // [CW], then shift [CW]
+    float* shift = scale + CW;
+    const int o = tid % OW, pi = tid / OW;
+    const bool active = pi < PI;
+    h8 v[NP];
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int p = pi + u * PI;
+            v[u] = (h8)(half_t)0;
+            if (p < HW) v[u] = *(const h8*)src_octet(x0, C0, x1, C1, (size_t)b * HW + p, (c_lo >> 3) + o);
+        }
+        float sm[8], sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < NP; ++u)      // pixels past HW hold zeros: they add nothing
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; sm[e] += f; sq[e] += f * f; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((size_t)pi * CW + (o << 3) + e) * 2] = sm[e];
+            red[((size_t)pi * CW + (o << 3) + e) * 2 + 1] = sq[e];
+        }
+    }
+    __syncthreads();
+    // two-level fixed-order reduction, as in gn_fused_kernel: per channel over the pixel lanes, then per group over its channels
+    for (int i = tid; i < 2 * CW; i += 1024) {
+        float acc = 0.f;
+        for (int l = 0; l < PI; ++l) acc += red[(size_t)l * CW * 2 + i];
+        stats[8 + 2 * CW + i] = acc;                               // per-channel totals, behind scale / shift
+    }
+    __syncthreads();
+    const float* tot = stats + 8 + 2 * CW;
+    if (tid < 2 * NG) {
+        const int g = tid >> 1, which = tid & 1;
+        double acc = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += (double)tot[c * 2 + which];
+        stats[tid] = (float)(acc / ((double)HW * cpg));            // E[x], E[x^2] of group g
+    }
+    __syncthreads();
+    if (tid < NG) {
+        const double mean = stats[2 * tid];
+        double var = (double)stats[2 * tid + 1] - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < CW; c += 1024) {
+        const int g = c / cpg;
+        const float w = gamma[c_lo + c] * stats[2 * g + 1];
+        scale[c] = w;
+        shift[c] = beta[c_lo + c] - stats[2 * g] * w;
+    }
+    __syncthreads();
+    if (active) {
+        const f32x4 sc0 = *(const f32x4*)(scale + (o << 3)), sc1 = *(const f32x4*)(scale + (o << 3) + 4);
+        const f32x4 sh0 = *(const f32x4*)(shift + (o << 3)), sh1 = *(const f32x4*)(shift + (o << 3) + 4);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int p = pi + u * PI;
+            if (p < HW) {
+                h8 r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[u][e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                    if (silu) f = silu_f(f);
+                    r[e] = (half_t)f;
+                }
+                *(h8*)(out + ((size_t)b * HW + p) * C + c_lo + (o << 3)) = r;
+            }
+        }
+    }
+}
+
 size_t groupnorm_ws_floats(int B, int HW) {
     const int nchunk = (HW + 63) / 64;   // upper bound for every chunk size >= 64
     return (size_t)B * nchunk * 64 + (size_t)B * 64;
@@ -273,10 +374,46 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
                     return FGDM_ERR_HIP;
                 attr_set = true;
             }
-            if (NT == 512) FGDM_LAUNCH(gn_fused_kernel<512>, dim3(32 / NG, B), dim3(512), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma,
+            const dim3 gridf((32 / NG) * 8 * ((B + 7) / 8));
+            if (NT == 512) FGDM_LAUNCH(gn_fused_kernel<512>, gridf, dim3(512), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma,
                                               beta, silu, out);
-            else FGDM_LAUNCH(gn_fused_kernel<256>, dim3(32 / NG, B), dim3(256), smem, s, x0, C0, x1, C1, HW, NG, eps, gamma, beta,
+            else FGDM_LAUNCH(gn_fused_kernel<256>, gridf, dim3(256), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta,
                                     silu, out);
+            return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+        }
+    }
+    // register-resident single pass for the fine levels: the narrowest whole-group slice whose pieces fit a thread's registers
+    {
+        // measured, B = 32 / 16 (tools/bench_norm.py, us, two kernels -> this one): 32x32 C = 640 28.8 -> 20.5 / 20.6 -> 16.9,
+        // 640+640 45.0 -> 34.4 / 31.2 -> 27.8, 1280+640 67.1 -> 55.0.  The 64x64 level stays on two kernels: C = 320 50.7 -> 45.8 at
+        // B = 32 but 32.1 -> 34.9 at B = 16, 320+320 (sixteen slices per sample, two rounds of workgroups) 94.4 -> 107.3, and nothing
+        // end to end (which kernel runs must not depend on the batch: a sample's bits must not)
+        static const int reg_hw = getenv("FGDM_GN_REG") ? atoi(getenv("FGDM_GN_REG")) : 1024;      // A/B knob: largest HW taken (0 = off)
+        const bool reg_on = HW <= reg_hw;
+        const int cpg = C >> 5;
+        for (int NG = 4; reg_on && NG >= 1; NG >>= 1) {           // the widest slice that fits: longer runs per pixel row
+            const int CW = NG * cpg;
+            if (CW & 7) continue;
+            const int OW = CW >> 3;
+            if (OW < 5 || OW > 64) continue;                       // (narrower: 16-64 byte runs per pixel row, the autoencoder's widths)
+            const int PI = 1024 / OW, np = (HW + PI - 1) / PI;
+            if (np > 21) continue;
+            const size_t smem = ((size_t)PI * CW * 2 + 8 + 2 * (size_t)CW + 2 * (size_t)CW) * sizeof(float);
+            if (smem > 150 * 1024) continue;
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)gn_reg_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_reg_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_reg_kernel<21>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                    return FGDM_ERR_HIP;
+                attr_set = true;
+            }
+            const dim3 grid((32 / NG) * 8 * ((B + 7) / 8)), block(1024);
+            if (np <= 6) FGDM_LAUNCH(gn_reg_kernel<6>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
+            else if (np <= 11) FGDM_LAUNCH(gn_reg_kernel<11>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
+            else if (np <= 16) FGDM_LAUNCH(gn_reg_kernel<16>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
+            else FGDM_LAUNCH(gn_reg_kernel<21>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
             return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
         }
     }

@@ -148,7 +148,11 @@ GN_CASES = [(2, 64, 320, 0, 1e-5, 1), (2, 64, 1280, 640, 1e-5, 1), (1, 16, 1280,
             # 82 KB slices (two-kernel path since round 2), a 41 KB slice (single kernel, second choice), ragged pixel counts,
             # the autoencoder's 128-channel full-resolution level (4 channels per group)
             (2, 1024, 640, 0, 1e-5, 1), (2, 1024, 1280, 0, 1e-5, 1), (1, 256, 1280, 1280, 1e-5, 1),
-            (1, 1000, 320, 0, 1e-5, 1), (1, 999, 640, 640, 1e-6, 0), (1, 16384, 128, 0, 1e-6, 1)]
+            (1, 1000, 320, 0, 1e-5, 1), (1, 999, 640, 640, 1e-6, 0), (1, 16384, 128, 0, 1e-6, 1),
+            # the register-resident single pass (64x64 / 32x32 levels): every piece count, concat sources inside and across slices,
+            # ragged pixel counts, and a width that falls back to two kernels at 64x64 (960)
+            (2, 4096, 320, 320, 1e-5, 1), (1, 4096, 640, 320, 1e-5, 1), (2, 1024, 1280, 640, 1e-5, 1), (2, 1024, 640, 320, 1e-6, 0),
+            (1, 4090, 320, 0, 1e-5, 1), (2, 1024, 320, 0, 1e-5, 1), (1, 2000, 640, 0, 1e-5, 1)]
 
 
 @pytest.mark.parametrize('case', GN_CASES, ids=[f'B{c[0]}_HW{c[1]}_C{c[2]}+{c[3]}' for c in GN_CASES])

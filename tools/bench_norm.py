@@ -12,7 +12,7 @@ from fgdm_amd import _lib
 # kind (0 GroupNorm+SiLU, 1 LayerNorm), B, HW, C0, C1
 SHAPES = [(0, 32, 4096, 320, 0), (0, 32, 4096, 320, 320), (0, 32, 4096, 640, 320), (0, 32, 1024, 640, 0), (0, 32, 1024, 640, 640),
           (0, 32, 1024, 1280, 640), (0, 32, 256, 1280, 0), (0, 32, 256, 1280, 1280), (0, 32, 64, 1280, 0), (0, 32, 64, 1280, 1280),
-          (0, 16, 4096, 320, 0), (0, 16, 64, 1280, 0),
+          (0, 16, 4096, 320, 0), (0, 16, 1024, 640, 0), (0, 16, 1024, 640, 640), (0, 16, 64, 1280, 0), (0, 2, 1024, 640, 0),
           (1, 32, 4096, 320, 0), (1, 32, 1024, 640, 0), (1, 32, 256, 1280, 0), (1, 32, 64, 1280, 0)]
 
 
