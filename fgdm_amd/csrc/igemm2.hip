@@ -590,8 +590,10 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
                 if constexpr (GEGLU) {      // packed rows: 64-row groups [32 value | 32 gate]
                     constexpr int GJ = MS == 32 ? 1 : 2;                 // gate tile = value tile + GJ
                     const f32x4 gq = *(const f32x4*)(bw + wc + 32);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_f(acc[j + GJ][i][g * 4 + e] + gq[e]);
+                    // two gates per call: the polynomial issues as packed fp32 (same operations, same bits as gelu_f)
+                    const f32x2 g01 = gelu2_f(f32x2{acc[j + GJ][i][g * 4] + gq[0], acc[j + GJ][i][g * 4 + 1] + gq[1]});
+                    const f32x2 g23 = gelu2_f(f32x2{acc[j + GJ][i][g * 4 + 2] + gq[2], acc[j + GJ][i][g * 4 + 3] + gq[3]});
+                    v[0] *= g01[0]; v[1] *= g01[1]; v[2] *= g23[0]; v[3] *= g23[1];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= a.scale;
