@@ -108,6 +108,9 @@ struct IgemmArgs {
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s);
 void igemm_set_force_cfg(int cfg);   // process-wide override of the tile choice (0 = automatic)
+void igemm_set_twin_layers(bool on);  // the layers walked from now on have a same-shape twin in another net of this engine (UNet
+                                       // encoder / middle block and the ControlNets): igemm_splitk_factor leaves their K = 11520
+                                       // convolutions of the 16x16 level whole, whichever way the twins are launched
 void igemm_set_pair_hint(int mult);  // launches recorded from now on will be fused `mult` at a time (grid size for the tile choice)
 int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s);
 int igemm_stats_slots(const IgemmArgs& a);    // > 0: igemm_launch(a) will fill a.stats_out with that many slots per row; 0: it cannot

@@ -1550,6 +1550,7 @@ struct fgdm_engine {
                        std::vector<Tensor>* hs, Tensor* h_mid, bool only_mid, float* out32, int64_t out_cap, bool pairs = false,
                        std::vector<Deferred>* defer = nullptr) {
         const int B = x4.B;
+        struct TwinGuard { TwinGuard() { igemm_set_twin_layers(true); } ~TwinGuard() { igemm_set_twin_layers(false); } } twin_guard;
         // CFG pairs: rows b and b + B/2 carry the same x, t and hint -> input blocks 0 and 1 (up to the first
         // cross-attention) are evaluated once on B/2 rows
         const bool shared = pairs && !out32 && 2 * n.guided.B == B && n.input.size() > 1;
@@ -1684,6 +1685,8 @@ struct fgdm_engine {
             if (hipEventRecord(ev_join, s2) != hipSuccess) return fail(FGDM_ERR_HIP, "stream join");
         }
         // ---- encoder (openaimodel.py:849-858); the adapter feature is added BEFORE the skip is recorded
+        struct TwinOff { ~TwinOff() { igemm_set_twin_layers(false); } } twin_off;      // whatever path leaves
+        igemm_set_twin_layers(with_cn);             // encoder + middle block: the ControlNets' twins (a ControlNet walk ends with it off)
         std::vector<Tensor> hs;
         Tensor h;
         int k = 0;
@@ -1718,6 +1721,7 @@ struct fgdm_engine {
         }
         Tensor hm;
         CHK(block_fwd(n.middle, h, false, nullptr, ec, ctx16, nullptr, &hm));
+        igemm_set_twin_layers(false);
         // ---- ControlNets: residuals accumulate in place into hs / hm (cldm.py:40,46,846)
         if (paired) {
             g_rec = nullptr;

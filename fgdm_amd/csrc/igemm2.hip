@@ -855,14 +855,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a) {
 // Split K for the long-contraction layers of the coarse latent levels (8x8 positions per sample: M = 64 B rows cannot fill
 // the chip with 128-row tiles; 16x16: not with 256-row tiles).  The decision depends ONLY on the per-sample geometry and K -- never on
 // the batch size -- so a sample's result stays bit-identical whatever batch (or rank shard) it is evaluated in.
+static thread_local bool g_twin_layers = false;
+void igemm_set_twin_layers(bool on) { g_twin_layers = on; }
+
 int igemm_splitk_factor(const IgemmArgs& a) {
     if (a.force_cfg || a.act == ACT_GEGLU || a.out_kind != OUT_F16 || a.N % 320 || (a.K & 31)) return 1;
     const int nk = a.K >> 5;
     static const bool fat = !(getenv("FGDM_SPLITK_FAT") && atoi(getenv("FGDM_SPLITK_FAT")) == 0);          // A/B knob
-    // the decoder's concat convolutions of the 16x16 level (K >= 17280; they have no ControlNet twin to share a launch with): two
-    // ways, so that at B = 32 they fill the chip with 256 x 320 tiles (2560->1280: 576 -> 479 us with the reduction pass; three or
-    // four ways 551 / 509).  The K = 11520 layers of that level stay whole: the encoder's run as twin launches on fat tiles already
-    if (fat && a.rows_per_sample > 64 && a.rows_per_sample <= 256 && nk >= 540) return 2;
+    // the decoder's convolutions of the 16x16 level (they have no ControlNet twin to share a launch with): two ways, so that at
+    // B = 32 they fill the chip with 256 x 320 tiles (2560->1280: 576 -> 479 us with the reduction pass; three or four ways 551 /
+    // 509; 1280->1280: 301 -> ~255).  The K = 11520 layers WITH a twin stay whole: as twin launches they are on fat tiles already
+    // (220 us each).  "Has a twin" is a property of the layer in this engine (igemm_set_twin_layers), not of how it is launched
+    if (fat && a.rows_per_sample > 64 && a.rows_per_sample <= 256 && (nk >= 540 || (nk >= 360 && !g_twin_layers))) return 2;
     if (a.rows_per_sample > 64 || nk < 96) return 1;
     // the 3x3 convolutions of that level (K >= 11520) split eight ways: at B = 32 that is what lets them run on 256 x 320 tiles
     // (igemm_launch), two thirds of the L2 -> LDS bytes of the 128-row tiles (same box, B = 32: 1280->1280 88 -> 84 us,

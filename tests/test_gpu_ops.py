@@ -66,6 +66,7 @@ CONV_CASES = [
     (25, 8, 8, 1280, 1280, 1280, 3, 1, 0, 0, 'split-K x8 on 256x320 tiles, decoder concat, M tail (B=25)'),
     (2, 16, 16, 1280, 640, 1280, 3, 1, 0, 0, 'split-K x2 (16x16, K=17280) thin tiles rowvec + resid'),
     (25, 16, 16, 1280, 1280, 1280, 3, 1, 0, 1, 'split-K x2 on 256x320 tiles (16x16, K=23040, B=25) silu'),
+    (9, 16, 16, 1280, 0, 1280, 3, 1, 0, 0, 'split-K x2 (16x16, K=11520, a layer without a twin) rowvec + resid'),
 ]
 
 
