@@ -351,39 +351,9 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
                      const float* beta, float eps, int silu, half_t* out, float* ws, hipStream_t s) {
     const int C = C0 + C1;
     if ((C & 31) || (C0 & 7) || (C1 & 7) || C > 4096 || B <= 0 || HW <= 0 || (size_t)HW * (C >> 3) >= (1u << 31)) return FGDM_ERR_ARG;
-    // single-kernel path when NG whole groups of one sample fit in LDS
-    {
-        const int cpg = C >> 5;
-        // first choice: slices of <= 40 KB (3+ workgroups per CU overlap their load / apply phases), else up to 64 KB (two per
-        // CU).  Fatter slices (82 KB at the 32x32 level: one workgroup per CU, its load, reduce and store phases back to back)
-        // measured 37.5 us for an 84 MB pass where the two-kernel path below moves 126 MB in about 25
-        static const int max_kb = getenv("FGDM_GN_FUSED_MAXKB") ? atoi(getenv("FGDM_GN_FUSED_MAXKB")) : 64;      // tuning knob
-        for (int pass = 0; pass < 2; ++pass)
-        for (int NG = 4; NG >= 1; NG >>= 1) {
-            const int CW = NG * cpg;
-            const size_t slice = (size_t)HW * CW * 2;
-            if ((CW & 7) || CW > 320 || slice > (size_t)std::min(pass == 0 ? 40 : 64, max_kb) * 1024) continue;
-            const int NT = slice > 40 * 1024 ? 512 : 256;      // one fat slice per CU: twice the threads (and loads in flight)
-            const int OW = CW >> 3, PI = NT / OW;
-            const size_t smem = slice + ((size_t)PI * CW * 2 + 8 + 2 * (size_t)CW) * sizeof(float);
-            if (smem > 150 * 1024) continue;
-            static bool attr_set = false;
-            if (!attr_set) {
-                if (hipFuncSetAttribute((const void*)gn_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)gn_fused_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-                    return FGDM_ERR_HIP;
-                attr_set = true;
-            }
-            const dim3 gridf((32 / NG) * 8 * ((B + 7) / 8));
-            if (NT == 512) FGDM_LAUNCH(gn_fused_kernel<512>, gridf, dim3(512), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma,
-                                              beta, silu, out);
-            else FGDM_LAUNCH(gn_fused_kernel<256>, gridf, dim3(256), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta,
-                                    silu, out);
-            return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
-        }
-    }
-    // register-resident single pass for the fine levels: the narrowest whole-group slice whose pieces fit a thread's registers
-    {
+    // register-resident single pass (gn_reg_kernel): the widest whole-group slice whose pieces fit a thread's registers.
+    // Returns 1 when no slice fits (the caller goes on to the other paths), else the launch status.
+    auto try_reg = [&]() -> int {
         // measured, B = 32 / 16 (tools/bench_norm.py, us, two kernels -> this one): 32x32 C = 640 28.8 -> 20.5 / 20.6 -> 16.9,
         // 640+640 45.0 -> 34.4 / 31.2 -> 27.8, 1280+640 67.1 -> 55.0.  The 64x64 level stays on two kernels: C = 320 50.7 -> 45.8 at
         // B = 32 but 32.1 -> 34.9 at B = 16, 320+320 (sixteen slices per sample, two rounds of workgroups) 94.4 -> 107.3, and nothing
@@ -416,7 +386,43 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
             else FGDM_LAUNCH(gn_reg_kernel<21>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
             return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
         }
+        return 1;
+    };
+    // from 16x16 x 1280 channels (or 8x8 x 2560) upwards the register kernel is the faster single pass (tools/bench_norm.py, B = 32,
+    // LDS kernel -> register kernel: 16x16 C = 1280 15.6 -> 14.4 us, 2560 33.5 -> 22.5; 8x8 C = 2560 13.4 -> 12.1, C = 1280 8.9 -> 9.1)
+    if ((size_t)HW * C >= 64 * 2560) { const int rc = try_reg(); if (rc != 1) return rc; }
+    // single-kernel path when NG whole groups of one sample fit in LDS
+    {
+        const int cpg = C >> 5;
+        // first choice: slices of <= 40 KB (3+ workgroups per CU overlap their load / apply phases), else up to 64 KB (two per
+        // CU).  Fatter slices (82 KB at the 32x32 level: one workgroup per CU, its load, reduce and store phases back to back)
+        // measured 37.5 us for an 84 MB pass where the two-kernel path below moves 126 MB in about 25
+        static const int max_kb = getenv("FGDM_GN_FUSED_MAXKB") ? atoi(getenv("FGDM_GN_FUSED_MAXKB")) : 64;      // tuning knob
+        for (int pass = 0; pass < 2; ++pass)
+        for (int NG = 4; NG >= 1; NG >>= 1) {
+            const int CW = NG * cpg;
+            const size_t slice = (size_t)HW * CW * 2;
+            if ((CW & 7) || CW > 320 || slice > (size_t)std::min(pass == 0 ? 40 : 64, max_kb) * 1024) continue;
+            const int NT = slice > 40 * 1024 ? 512 : 256;      // one fat slice per CU: twice the threads (and loads in flight)
+            const int OW = CW >> 3, PI = NT / OW;
+            const size_t smem = slice + ((size_t)PI * CW * 2 + 8 + 2 * (size_t)CW) * sizeof(float);
+            if (smem > 150 * 1024) continue;
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)gn_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_fused_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                    return FGDM_ERR_HIP;
+                attr_set = true;
+            }
+            const dim3 gridf((32 / NG) * 8 * ((B + 7) / 8));
+            if (NT == 512) FGDM_LAUNCH(gn_fused_kernel<512>, gridf, dim3(512), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma,
+                                              beta, silu, out);
+            else FGDM_LAUNCH(gn_fused_kernel<256>, gridf, dim3(256), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta,
+                                    silu, out);
+            return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+        }
     }
+    { const int rc = try_reg(); if (rc != 1) return rc; }
     const int ppc = GN_PIX_PER_CHUNK;
     const int nchunk = (HW + ppc - 1) / ppc;
     float* partial = ws;
