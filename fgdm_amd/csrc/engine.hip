@@ -288,7 +288,7 @@ struct fgdm_engine {
     // FGDM_TWIN_STREAMS=1: the ControlNets run on a second stream (own arena: an arena's block reuse relies on stream order) next
     // to the UNet encoder + middle block, which they do not depend on (cldm.py:40,46: the UNet takes `control` only after its middle
     // block); their zero-convs are applied on the main stream behind a join event
-    Arena arena2;
+    Arena arena2, arena3;       // the ControlNets' workspaces (second stream / recorded walks); arena3: see apply_model, grouped launches
     Arena* ar = &arena;           // arena of the stream being enqueued
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -297,7 +297,7 @@ struct fgdm_engine {
     // launches") and replayed in lockstep on the one stream, twin GEMM launches fused into grouped launches (replay_zip)
     bool pair_launch = true;
     long paired_launches = 0, replayed_launches = 0;
-    struct Deferred { const GemmW* w; Tensor src; int idx; float scale; };
+    struct Deferred { const GemmW* w; Tensor src; int idx; float scale; Arena* owner; };
     Prof prof;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -1573,7 +1573,7 @@ struct fgdm_engine {
             }
             if (idx >= 0 && only_mid) return FGDM_OK;
             e.scale = scales ? scales[idx < 0 ? (int)n.input.size() : idx] : 1.f;
-            if (defer) { defer->push_back({&zw, src, idx, e.scale}); return FGDM_OK; }     // applied by the caller on the main stream
+            if (defer) { defer->push_back({&zw, src, idx, e.scale, ar}); return FGDM_OK; }     // applied by the caller on the main stream
             return zero_conv_into(zw, src, idx < 0 ? *h_mid : (*hs)[idx], e.scale);
         };
         for (size_t i = 0; i < n.input.size(); ++i) {
@@ -1660,9 +1660,13 @@ struct fgdm_engine {
         if (paired) {
             static const bool fat = !(getenv("FGDM_PAIR_FAT_TILES") && atoi(getenv("FGDM_PAIR_FAT_TILES")) == 0);       // A/B knob
             if (fat) igemm_set_pair_hint(2);
-            ar = &arena2;
             int rc = FGDM_OK;
             for (size_t c = 0; c < cns.size() && rc == FGDM_OK; ++c) {
+                // A recorded walk hands blocks out and takes them back at RECORD time, so two walks recorded one after the other from
+                // one arena share blocks -- harmless when they are also replayed one after the other (ControlNet 0, zipped with the
+                // UNet, is done before 1 starts), fatal when they are replayed INTERLEAVED: the pairs (1, 2), (3, 4) ... take their
+                // second member's workspace from another arena (three ControlNets at full size gave non-finite latents without it)
+                ar = (c >= 2 && c % 2 == 0) ? &arena3 : &arena2;
                 g_rec = &rec_cn[c];
                 rc = controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, nullptr, nullptr, false, nullptr, 0, pairs,
                                     &deferred);
@@ -1738,7 +1742,7 @@ struct fgdm_engine {
             for (const Deferred& d : deferred) CHK(zero_conv_into(*d.w, d.src, d.idx < 0 ? hm : hs[d.idx], d.scale));
             // the ControlNets' block outputs go back to their own arena: its next user is the next call's second stream, which
             // waits for that call's fork event, recorded behind these zero-convs
-            for (Deferred& d : deferred) { arena2.release(d.src.p); d.src.p = nullptr; }
+            for (Deferred& d : deferred) { d.owner->release(d.src.p); d.src.p = nullptr; }
         } else if (with_cn) {
             for (size_t c = 0; c < cns.size(); ++c)
                 CHK(controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, &hs, &hm,
@@ -1973,12 +1977,14 @@ template <typename F> static int scoped_call(fgdm_engine* e, void* stream, F f) 
     e->ar = &e->arena;
     e->arena.begin_scope();
     e->arena2.begin_scope();
+    e->arena3.begin_scope();
     const int rc = f();
     e->s = as_stream(stream);
     e->ar = &e->arena;
     if (rc != FGDM_OK && e->s2) (void)hipStreamSynchronize(e->s2);      // nothing of the second stream may outlive its blocks
     e->arena.end_scope(rc != FGDM_OK);
     e->arena2.end_scope(rc != FGDM_OK);
+    e->arena3.end_scope(rc != FGDM_OK);
     return rc;
 }
 

@@ -369,21 +369,23 @@ def test_broadcast_layout_is_bit_identical_to_fp32_load():
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
+@pytest.mark.parametrize('ncn', [2, 3])
 @pytest.mark.parametrize('knob', ['FGDM_PAIR_LAUNCH', 'FGDM_TWIN_STREAMS'])
-def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, monkeypatch):
+def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, ncn, monkeypatch):
     """The UNet encoder and the ControlNets are independent until the UNet's middle block (cldm.py:40,46).  Default: both walks are
     recorded and replayed in lockstep, twin GEMM launches fused into grouped launches (FGDM_PAIR_LAUNCH, on); opt-in: the ControlNets
-    on a second stream (FGDM_TWIN_STREAMS).  Neither may change a bit of eps: same kernels, same order per net."""
+    on a second stream (FGDM_TWIN_STREAMS).  Neither may change a bit of eps: same kernels, same order per net.  Three ControlNets:
+    the second and third are replayed INTERLEAVED with each other (their recorded walks must not share workspace blocks)."""
     from fgdm_amd.engine import Engine
     x, ctx = gi.get('small/x')[:2, :, :32, :32].contiguous(), gi.get('small/ctx')[:2]
-    hints = [gi.hint(2, 256, seed=5 + k) for k in range(2)]
+    hints = [gi.hint(2, 256, seed=5 + k) for k in range(ncn)]
     t = torch.tensor([981, 21])
     outs = []
     for val in ('0', '1'):
         monkeypatch.setenv(knob, val)
         if knob == 'FGDM_TWIN_STREAMS':
             monkeypatch.setenv('FGDM_PAIR_LAUNCH', '0')
-        e = Engine(gi.SMALL_CFG, n_controlnets=2)           # the knobs are read at fgdm_create
+        e = Engine(gi.SMALL_CFG, n_controlnets=ncn)         # the knobs are read at fgdm_create
         try:
             for k, shp in e.param_shapes().items():
                 e.load_tensor(k, synth.make_tensor(small_rename(k), shp))
