@@ -147,7 +147,7 @@ def main():
     ap.add_argument('--ddim-steps', type=int, default=DDIM_STEPS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--controlnets', type=int, default=1,
-                    help='control models per UNet (1 = the metric\'s config C3; 2 / 3 = BASELINE configs C4 / C5, use --prompts 8)')
+                    help='control models per UNet (1 = the metric\'s config C3; 2 / 3 = BASELINE configs C4 / C5, use --prompts 8; 0 = the plain UNet, C2)')
     ap.add_argument('--no-first-stage', action='store_true',
                     help='skip the VAE decode that follows the timed region (PMC passes: counters then cover the path only)')
     ap.add_argument('--profile-stride', type=int, default=7,
@@ -235,8 +235,9 @@ def main():
             return sampler.sample(a.ddim_steps, npg, (4, lat, lat), conditioning=cond, verbose=False, eta=0.0, x_T=x_T,
                                   unconditional_guidance_scale=CFG_SCALE, unconditional_conditioning=uncond)[0]
         # the call the reference makes at controlnet/initialize_cn.py:86-96 (guess_mode=False: control on both branches)
-        c_cond = {'c_concat': hints, 'c_crossattn': [cond]}
-        c_uncond = {'c_concat': hints, 'c_crossattn': [uncond]}
+        # --controlnets 0 (the plain UNet, BASELINE configs[1]): c_concat = None as in cldm.py:840-842
+        c_cond = {'c_crossattn': [cond], 'c_concat': hints if hints else None}
+        c_uncond = {'c_crossattn': [uncond], 'c_concat': hints if hints else None}
         out, _ = sampler.sample(a.ddim_steps, npg, (4, LATENT, LATENT), c_cond, verbose=False, eta=0.0, x_T=x_T,
                                 unconditional_guidance_scale=CFG_SCALE, unconditional_conditioning=c_uncond)
         return out
