@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ Q,
     // Cross-attention (Tk <= 128: K / Vt of a head are 6-25 KB, nothing to share) is bound by its Q reads and O writes, and a
     // head's slice of a token row is 2 D bytes of a 2 H D-byte row: there the HEAD runs fastest, so the H workgroups that touch
     // the same 128 rows are neighbours on one XCD and every 128-byte line of Q and O crosses the fabric once instead of once per
-    // head that owns a piece of it (T = 4096, d = 40: 80 -> see DESIGN.md section 4.3)
+    // head that owns a piece of it (only Tk <= 64 still comes here with few keys; the text tokens have attn_cross_kernel below)
     int qblk, b, head;
     if (Tk <= 128) {
         head = logical % H;
