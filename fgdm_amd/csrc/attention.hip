@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#pragma clang diagnostic ignored "-Winline-asm"     // M0 named as an asm clobber (att_dma16): reserved register, on purpose
 #define ATT_THR 8.0f
 
 template <int D>
@@ -887,6 +888,348 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const half_t* __restrict__
     }
 }
 
+// =====================================================================================================================
+// Two-strand kernel for long self-attention (round 4).  What bounds the kernels above at d = 40 is the SUM of a wave's matrix and
+// vector-ALU time (vector instructions of ANOTHER wave hardly enter a wave's MFMA shadows; instructions of the
+// SAME wave do), and 1.4x the algorithmic MFMAs.  Here one wave owns 64 queries as two independent 32-query STRANDS A and B, and its
+// instruction stream is written so that every MFMA of one strand is followed by softmax work of the other:
+//   * S^T = K Q^T stays on v_mfma_f32_32x32x16_f16 (keys on the rows, d = 40 -> 48 with the scale / running-max fold in slot 40),
+//     but O^T += V^T P^T runs on v_mfma_f32_16x16x32_f16: three 16-row tiles cover d = 40 (+ the ones row) instead of two 32-row
+//     tiles, 192 instead of 256 matrix cycles per 32 x 64 block.  The fp16 probabilities reach the B-operand layout of the 16-wide
+//     shape by FOUR v_permlane16_swap per 32 keys: lane n keeps the key groups of query n, lane n + 16 hands over its own in
+//     exchange -- and the K rows of a tile sit in LDS in the order that makes every lane group's eight keys CONTIGUOUS in V^T, so a
+//     V^T fragment is one ds_read_b128;
+//   * K / V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4) into a ring of 64-key slots, two tiles ahead, one raw s_barrier
+//     per tile: no staging registers, no ds_write, no second barrier.  Both images are ROW-major like their sources (a wave
+//     instruction fetches whole rows), conflict-free for the fragment reads: K rows of 80 bytes (20 banks: sixteen consecutive rows
+//     tile the 64 banks), V^T rows of 128 bytes with their 16-byte pieces XOR-swizzled on the SOURCE side by (row >> 1) & 7;
+//     the constant pieces (K[:, 40] = 1, the ones row of V^T, zero padding) live in 48 bytes of LDS that the pad lanes read instead;
+//   * NW = 4 waves per workgroup (256 queries), two workgroups per CU: the two waves of a SIMD belong to different workgroups and
+//     drift apart instead of meeting at the same barrier; NW = 8: one workgroup of 512 queries per CU, half the L2 -> LDS bytes.
+// Needs T % (64 NW) == 0 and Tk % 64 == 0 (the self-attention shapes).
+__device__ __forceinline__ void att_dma16(unsigned voff, const void* sbase, unsigned lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_addr) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void att_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ABL: ablation switches for tools/bench_attention.py (FGDM_ATTN_ABL; results are then meaningless): 1 = no exponentials,
+// 2 = no maximum / offset decision, 4 = no LDS-DMA after the first two tiles, 16 = no V^T P^T MFMAs, 32 = no K Q^T MFMAs
+template <int D, int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 2) void attn_dq_kernel(const half_t* __restrict__ Q, int ldq,
+                                                         const half_t* __restrict__ K, int ldk,
+                                                         const half_t* __restrict__ Vt, int ldvt,
+                                                         half_t* __restrict__ O, int ldo,
+                                                         int H, int T, int Tk, float sl2e) {
+    constexpr int DP = (D + 16) / 16 * 16, NKS = DP / 16;    // contraction length of K Q^T incl. the fold slot; k-steps of 16
+    constexpr int DT = DP / 16;                              // 16-row tiles of O^T; row D carries the softmax denominator
+    constexpr int DC = D / 8;                                // 16-byte pieces per K row
+    constexpr int PS = D / 16, PH = (D % 16) / 8;            // fragment / lane half of contraction slot D
+    constexpr int KROW = DC * 16, KBYTES = 64 * KROW, VBYTES = D * 128, SLOT = KBYTES + VBYTES;
+    constexpr int NSLOT = 3;
+    constexpr int NDMA = SLOT / 1024, NI = (NDMA + NW - 1) / NW;   // 1 KiB LDS-DMA wave-instructions per tile; per wave
+    static_assert(KBYTES % 1024 == 0 && VBYTES % 1024 == 0 && NDMA >= NW, "whole wave-instructions per image");
+    static_assert((KROW / 4) % 8 == 4, "K row stride: 4 mod 8 dwords so that sixteen consecutive rows tile the banks");
+    __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT + 64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, h = lane >> 5;                // S^T layout: query on lane & 31, key half on lane >> 5
+    const int n16 = lane & 15, g = lane >> 4;                // O^T layout: query on lane & 15, row quad on lane >> 4
+    const int nqb = T / (NW * 64);
+    const int nb = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qd = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
+    }
+    const int qblk = logical % nqb, bh = logical / nqb;
+    const int b = bh / H, head = bh - b * H;
+    const int q0w = qblk * (NW * 64) + wave * 64;                  // first query of this wave; strand X: q0w + 32 X + [0, 32)
+    const int nt = Tk >> 6;
+
+    // constant pieces: [1 0 0 0 0 0 0 0] (K[:, D] of the fold), eight ones (row D of V^T), zeros
+    char* const cst = smem + NSLOT * SLOT;
+    if (tid < 3) {
+        h8 v = (h8)(half_t)0;
+        if (tid == 0) v[0] = (half_t)1;
+        if (tid == 1) v = (h8)(half_t)1;
+        *(h8*)(cst + tid * 16) = v;
+    }
+
+    // ---- LDS-DMA plan of this wave: wave-instruction j = wave + 4 u of a tile (a surplus one repeats the wave's previous piece:
+    // same bytes to the same address).  K piece L = 64 j + lane: LDS row L / DC (row order below), 16-byte piece L % DC;
+    // V^T piece L: row L / 8, LDS position L % 8 holds source piece (L % 8) ^ ((row >> 1) & 7).
+    // K row order inside a 32-key sub-tile: LDS row rho = 8 a + 4 b + c holds key 16 b + 4 a + c, so that the keys whose
+    // probabilities end up in lane group g of the 16-wide B operand (after the permlane16 swaps) are keys 8 g .. 8 g + 7.
+    const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
+    const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
+    unsigned voff[NI], ldst[NI];
+    bool isk[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        int j = wave + NW * u;
+        if (j >= NDMA) j -= NW;
+        isk[u] = j < DC * 64 * 16 / 1024;
+        ldst[u] = (unsigned)j * 1024u;
+        if (isk[u]) {
+            const int L = 64 * j + lane, rp = L / DC, c = L - rp * DC;
+            const int rho = rp & 31, key = (rp & 32) + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+            voff[u] = (unsigned)(key * ldk + c * 8) * 2u;
+        } else {
+            const int L = 64 * (j - KBYTES / 1024) + lane, d = L >> 3, x = L & 7;
+            voff[u] = (unsigned)(d * ldvt + ((x ^ ((d >> 1) & 7)) * 8)) * 2u;
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+    auto issue = [&](int t, auto slotc) {                    // tile t -> slot t % NSLOT
+        const char* kb = (const char*)(Kb + (size_t)t * 64 * ldk);
+        const char* vb = (const char*)(Vb + t * 64);
+        const unsigned base = lds0 + (unsigned)decltype(slotc)::value * SLOT;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) att_dma16(voff[u], isk[u] ? kb : vb, base + ldst[u]);
+    };
+    issue(0, std::integral_constant<int, 0>{});
+    if (nt > 1) issue(1, std::integral_constant<int, 1>{});
+
+    // ---- Q^T fragments (B operand of K Q^T), pre-scaled; slot D will carry -max
+    h8 qf[2][NKS];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const int c = 16 * s + 8 * h;
+            qf[X][s] = (h8)(half_t)0;
+            if (c < D) qf[X][s] = *(const h8*)(Q + ((size_t)b * T + q0w + 32 * X + n32) * ldq + head * D + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[X][s][e] = (half_t)((float)qf[X][s][e] * sl2e);
+        }
+    f32x4 oacc[2][DT][2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) oacc[X][t][qg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {0.f, 0.f};
+
+    // ---- fragment addresses inside a slot.  K: row (32 sub + n32), piece 2 s + h -> immediate offsets 2560 sub + 32 s;
+    // pieces >= DC are the constants.  V^T: row 16 t + n16, source piece 4 sub + g at position (4 sub + g) ^ ((n16 >> 1) & 7).
+    const int k_lane = n32 * KROW + h * 16;
+    const int v_lane0 = KBYTES + n16 * 128 + ((g ^ ((n16 >> 1) & 7)) * 16);
+    const int v_lane1 = KBYTES + n16 * 128 + (((4 + g) ^ ((n16 >> 1) & 7)) * 16);
+    const char* const c_one = cst, *const c_ones = cst + 16, *const c_zero = cst + 32;
+
+    f32x16 sacc[2][2];
+    h8 kf[2][NKS], vf[DT][2], pb[2][2][2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define ATT_SB() __builtin_amdgcn_sched_barrier(0)
+    auto rd_k = [&](const char* sl, int sub, int s) {
+        const int ci0 = 2 * s;                               // piece index of lane half 0; half 1 reads ci0 + 1
+        const char* p = sl + k_lane + sub * 32 * KROW + s * 32;
+        if (ci0 + 1 >= DC) {                                 // some lanes read a constant piece
+            const char* cp0 = ci0 < DC ? p : (ci0 == DC ? c_one : c_zero);
+            const char* cp1 = ci0 + 1 == DC ? c_one : c_zero;
+            p = h ? cp1 : cp0;
+        }
+        kf[sub][s] = *(const h8*)p;
+    };
+    auto rd_v = [&](const char* sl, int t, int sub) {
+        const char* p = sl + (sub ? v_lane1 : v_lane0) + t * 16 * 128;
+        if (16 * t + 15 >= D) {                              // rows >= D of the last tile: the ones row, then zeros
+            const int d = 16 * t + n16;
+            p = d < D ? p : (d == D ? c_ones : c_zero);
+        }
+        vf[t][sub] = *(const h8*)p;
+    };
+    auto qk = [&](int X, int sub, int s) {
+        if constexpr ((ABL & 32) != 0) { if (s == 0) asm volatile("" : "=v"(sacc[X][sub])); return; }
+        sacc[X][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sub][s], qf[X][s], s == 0 ? zero16 : sacc[X][sub], 0, 0, 0);
+    };
+    auto pv = [&](int X, int sub, int t, int qg) {
+        if constexpr ((ABL & 16) != 0) { asm volatile("" : "+v"(oacc[X][t][qg]) : "v"(vf[t][sub]), "v"(pb[X][sub][qg])); return; }
+        oacc[X][t][qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t][sub], pb[X][sub][qg], oacc[X][t][qg], 0, 0, 0);
+    };
+    auto max_part = [&](int X, int sub, float mx) {          // 8 v_max3 over one sub-tile's 16 scores of this lane
+        if constexpr ((ABL & 2) != 0) return mx;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[X][sub][r]), sacc[X][sub][r + 1]);
+        return mx;
+    };
+    auto max_cross = [&](float mx) {                         // the other key half of the same query: lane ^ 32
+        // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc folds fmaxf(r[0], r[1]) of the builtin's two results into r[0]
+        // (visible in the IR; round 3 met the same fold) and the cross-half maximum silently disappears.  s_nop 1 = the two wait
+        // states between a vector-ALU write of an operand and the swap that reads it
+        float lo = mx, hi = mx;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        return fmaxf(lo, hi);
+    };
+    // the offset moves only when some query of the strand outgrew it by more than 2^ATT_THR (or on the first tile)
+    auto decide = [&](int X, float mx, bool first) {
+        if constexpr ((ABL & 2) != 0) return;
+        if (first || !__all(mx <= ATT_THR)) {
+            const float m_new = first ? mx : m_run[X] + fmaxf(mx, 0.f);
+            const float m_hat = (float)(half_t)m_new;        // exactly what Q[q][D] can hold
+            const float delta = m_run[X] - m_hat;
+            m_run[X] = m_hat;
+            if (!first) {
+                const float alpha = __builtin_amdgcn_exp2f(delta);
+#pragma unroll
+                for (int qg = 0; qg < 2; ++qg) {             // O^T keeps query 16 qg + n16 on this lane: fetch ITS factor
+                    const float aq = __shfl(alpha, 16 * qg + n16);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) oacc[X][t][qg] *= aq;
+                }
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[X][sub][r] += delta;   // this tile was taken against the old offset
+            if (h == PH) qf[X][PS][0] = (half_t)(-m_hat);
+        }
+    };
+    auto expo = [&](int X, int sub, int r0, int r1) {
+#pragma unroll
+        for (int r = r0; r < r1; ++r) sacc[X][sub][r] = (ABL & 1) ? sacc[X][sub][r] : __builtin_amdgcn_exp2f(sacc[X][sub][r]);
+    };
+    // fp16 probabilities of one 32-key sub-tile -> the two B operands (queries 0-15 / 16-31 of the strand) of the 16-wide MFMA
+    auto pack = [&](int X, int sub) {
+        unsigned pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h2 t2 = {(half_t)sacc[X][sub][2 * i], (half_t)sacc[X][sub][2 * i + 1]};
+            pk[i] = __builtin_bit_cast(unsigned, t2);
+        }
+        u32x4 lo, hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto r2 = __builtin_amdgcn_permlane16_swap(pk[i], pk[i + 4], false, false);
+            lo[i] = r2[0]; hi[i] = r2[1];
+        }
+        pb[X][sub][0] = __builtin_bit_cast(h8, lo);
+        pb[X][sub][1] = __builtin_bit_cast(h8, hi);
+    };
+
+    // one tile; the ring slot is a compile-time constant (the loop below is unrolled over the slots), so every fragment address is
+    // a loop-invariant register plus an immediate
+    auto tile = [&](int kt, auto slotc) {
+        constexpr int slot = decltype(slotc)::value;
+        // my pieces of tile kt landed (tile kt + 1 may fly), then everybody's: one barrier per tile; behind it nobody reads the
+        // slot that tile kt + 2 goes to (the one of tile kt - 1) any more
+        if (!(ABL & 4) && kt + 1 < nt) att_wait_vmcnt<NI>(); else att_wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 4) && kt + 2 < nt) issue(kt + 2, std::integral_constant<int, (slot + 2) % NSLOT>{});
+        const char* sl = smem + slot * SLOT;
+        const bool first = kt == 0;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) rd_k(sl, sub, s);
+        ATT_SB();
+        // (b) K Q^T of strand A; the V^T fragments of the tile are requested between its MFMAs
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                qk(0, sub, s);
+                if (sub * NKS + s < DT * 2) rd_v(sl, (sub * NKS + s) % DT, (sub * NKS + s) / DT);
+                ATT_SB();
+            }
+        // (c) K Q^T of strand B  |  strand A: maximum, decision, exp and pack of its first 32 keys
+        float mx = sacc[0][0][0];                   // (sub-tile 0 first: its MFMAs retired three MFMAs ago)
+        qk(1, 0, 0); mx = max_part(0, 0, mx); ATT_SB();
+        qk(1, 0, 1); mx = max_part(0, 1, mx); ATT_SB();
+        qk(1, 0, 2 % NKS); mx = max_cross(mx); ATT_SB();
+#pragma unroll
+        for (int s = 3; s < NKS; ++s) { qk(1, 0, s); ATT_SB(); }
+        decide(0, mx, first);
+        ATT_SB();
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            qk(1, 1, s);
+            expo(0, 0, 16 * s / NKS, 16 * (s + 1) / NKS);
+            ATT_SB();
+        }
+        pack(0, 0);
+        ATT_SB();
+        // (d) V^T P^T of strand A, first 32 keys  |  strand A: exp of its second 32 keys; strand B: maximum
+        float mxb = sacc[1][0][0];
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) {
+                const int i = t * 2 + qg, n = DT * 2;
+                pv(0, 0, t, qg);
+                expo(0, 1, 16 * i / n, 16 * (i + 1) / n);
+                if (i == 1) mxb = max_part(1, 0, mxb);
+                if (i == 3) mxb = max_part(1, 1, mxb);
+                if (i == 4) mxb = max_cross(mxb);
+                ATT_SB();
+            }
+        pack(0, 1);
+        ATT_SB();
+        decide(1, mxb, first);
+        ATT_SB();
+        // (e) V^T P^T of strand A, second 32 keys  |  strand B: exp and pack of its first 32 keys
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) {
+                const int i = t * 2 + qg, n = DT * 2;
+                pv(0, 1, t, qg);
+                expo(1, 0, 16 * i / n, 16 * (i + 1) / n);
+                ATT_SB();
+            }
+        pack(1, 0);
+        ATT_SB();
+        // (f) V^T P^T of strand B, first 32 keys  |  strand B: exp and pack of its second 32 keys
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) {
+                const int i = t * 2 + qg, n = DT * 2;
+                pv(1, 0, t, qg);
+                expo(1, 1, 16 * i / n, 16 * (i + 1) / n);
+                ATT_SB();
+            }
+        pack(1, 1);
+        ATT_SB();
+        // (g) V^T P^T of strand B, second 32 keys
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) pv(1, 1, t, qg);
+        ATT_SB();
+    };
+    for (int kt = 0; kt < nt; kt += NSLOT) {
+        tile(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < nt) tile(kt + 1, std::integral_constant<int, 1>{});
+        if (kt + 2 < nt) tile(kt + 2, std::integral_constant<int, 2>{});
+    }
+#undef ATT_SB
+
+    // ---- O = O^T / l: row D of O^T (tile D / 16, row D % 16: lane group (D % 16) / 4, register D % 4) is the denominator
+    constexpr int LT = D / 16, LG = (D % 16) / 4, LR = D % 4;
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
+            const float l = __shfl(oacc[X][LT][qg][LR], 16 * LG + n16);
+            const float inv = 1.0f / l;
+            half_t* op = O + ((size_t)b * T + q0w + 32 * X + 16 * qg + n16) * ldo + head * D;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int dd = 16 * t + 4 * g;
+                if (dd < D) {
+                    const h4 o4 = {(half_t)(oacc[X][t][qg][0] * inv), (half_t)(oacc[X][t][qg][1] * inv),
+                                   (half_t)(oacc[X][t][qg][2] * inv), (half_t)(oacc[X][t][qg][3] * inv)};
+                    *(h4*)(op + dd) = o4;
+                }
+            }
+        }
+}
+
 int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* Vt, int ldvt, half_t* O,
                      int ldo, int B, int H, int T, int Tk, int d, int q_prescaled, hipStream_t s) {
     if (B <= 0 || H <= 0 || T <= 0 || Tk <= 0) return FGDM_ERR_ARG;
@@ -896,6 +1239,26 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
     const float sl2e = q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)d);
     // long self-attention: the eight-wave ping-pong kernel (256 queries per workgroup); FGDM_ATTN_PP=0 switches it off (A/B)
     static const bool pp_on = !(getenv("FGDM_ATTN_PP") && atoi(getenv("FGDM_ATTN_PP")) == 0);
+    // ... and the two-strand kernel where its shape conditions hold (FGDM_ATTN_DQ: 0 = off, 1 = plain, 2 = rotated tail)
+    static const int dq = getenv("FGDM_ATTN_DQ") ? atoi(getenv("FGDM_ATTN_DQ")) : 0;
+    const int dq_nw = dq == 2 ? 8 : 4;       // 1 = four waves per workgroup, 2 = eight
+    if (dq > 0 && d == 40 && T % (64 * dq_nw) == 0 && Tk % 64 == 0 && Tk >= 128 && (size_t)64 * ldk * 2 < (1u << 31) &&
+        (size_t)d * ldvt * 2 < (1u << 31)) {
+        const dim3 gridq((T / (64 * dq_nw)) * H * B), blockq(64 * dq_nw);
+        static const int abl = getenv("FGDM_ATTN_ABL") ? atoi(getenv("FGDM_ATTN_ABL")) : 0;
+        if (abl && dq_nw == 4) {
+            switch (abl) {
+#define ATT_ABL_CASE(v) case v: FGDM_LAUNCH((attn_dq_kernel<40, 4, v>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
+                ATT_ABL_CASE(1) ATT_ABL_CASE(2) ATT_ABL_CASE(3) ATT_ABL_CASE(4) ATT_ABL_CASE(16) ATT_ABL_CASE(32) ATT_ABL_CASE(48) ATT_ABL_CASE(51) ATT_ABL_CASE(7)
+#undef ATT_ABL_CASE
+                default: return FGDM_ERR_ARG;
+            }
+            return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+        }
+        if (dq_nw == 4) FGDM_LAUNCH((attn_dq_kernel<40, 4>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        else FGDM_LAUNCH((attn_dq_kernel<40, 8>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+    }
     if (pp_on && T >= 256 && Tk >= 256 && (d == 40 || d == 80)) {
         const dim3 grid2(((T + 255) / 256) * H * B), block2(512);
         if (d == 40) FGDM_LAUNCH(attn_pp_kernel<40>, grid2, block2, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#pragma clang diagnostic ignored "-Winline-asm"
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
 
@@ -28,15 +29,17 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_addr) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(g), "s"(lds_wave_addr)
-                 : "memory");
+                 : "memory", "m0");
 }
-// the same for the pipelined K loop, whose instruction stream is what bounds it: M0 is written and not restored (nothing else in
-// these kernels uses it: LDS instructions take no M0 on gfx9+), and the weight pieces use the SGPR-base + 32-bit VGPR offset form
+// the same for the pipelined K loop, whose instruction stream is what bounds it: M0 is written and not restored, which the "m0"
+// clobber tells the compiler (its own M0 users -- indexed register moves, sendmsg, the LDS-DMA builtin -- re-initialise M0 behind
+// such a statement instead of assuming it survived; LDS instructions take no M0 on gfx9+), and the weight pieces use the
+// SGPR-base + 32-bit VGPR offset form.  (-Winline-asm: M0 is a reserved register; naming it as a clobber is the point.)
 __device__ __forceinline__ void glds16_m0(const void* g, unsigned lds_wave_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_addr) : "memory", "m0");
 }
 __device__ __forceinline__ void glds16_sv(unsigned voff, const void* sbase, unsigned lds_wave_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_addr) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const void*)p; }
 // rstd (acc - mean u): one fma and one multiply as inline asm -- with -ffp-contract=fast the backend fuses a multiply into the
