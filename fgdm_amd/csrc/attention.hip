@@ -1230,6 +1230,299 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dq_kernel(const half_t* __res
         }
 }
 
+// The same two-strand structure with V^T P^T back on v_mfma_f32_32x32x16_f16 (round 4, after the ablations of the kernel above:
+// its time is the SUM of its vector-ALU issue cycles and 8 issue cycles per MFMA -- the matrix pipe's own time hides in the
+// shadows -- so what counts is the NUMBER of MFMAs and of vector instructions, not the matrix cycles): 8 MFMAs per 32 x 64 block
+// instead of 12, no permlane swaps (the S^T accumulators, converted, ARE the B operand), O^T as two 32-row tiles (d = 40 -> 64,
+// rows 41.. zero).  K rows sit in LDS in the order that makes the eight keys of a lane's B-operand slice contiguous in V^T, so a
+// V^T fragment is again one ds_read_b128.  The constant rows of V^T (ones row, zero rows) are part of the LDS image (written once
+// per slot; the DMA fills rows 0 .. D - 1 only), so only the K fragment of the fold slot needs a per-lane address.
+template <int D, int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 2) void attn_dq32_kernel(const half_t* __restrict__ Q, int ldq,
+                                                           const half_t* __restrict__ K, int ldk,
+                                                           const half_t* __restrict__ Vt, int ldvt,
+                                                           half_t* __restrict__ O, int ldo,
+                                                           int H, int T, int Tk, float sl2e) {
+    constexpr int DP = (D + 16) / 16 * 16, NKS = DP / 16;    // contraction length of K Q^T incl. the fold slot; k-steps of 16
+    constexpr int DT = (D + 32) / 32;                        // 32-row tiles of O^T; row D carries the softmax denominator
+    constexpr int DC = D / 8;                                // 16-byte pieces per K row
+    constexpr int PS = D / 16, PH = (D % 16) / 8;            // fragment / lane half of contraction slot D
+    constexpr int KROW = DC * 16, KBYTES = 64 * KROW, VDATA = D * 128, VBYTES = DT * 32 * 128, SLOT = KBYTES + VBYTES;
+    constexpr int NSLOT = 3;
+    constexpr int NDMA = (KBYTES + VDATA) / 1024, NI = (NDMA + NW - 1) / NW;   // 1 KiB LDS-DMA wave-instructions per tile; per wave
+    static_assert(KBYTES % 1024 == 0 && VDATA % 1024 == 0 && NDMA >= NW, "whole wave-instructions per image");
+    static_assert((KROW / 4) % 8 == 4, "K row stride: 4 mod 8 dwords so that sixteen consecutive rows tile the banks");
+    __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT + 64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, h = lane >> 5;                // query (S^T, O^T) / row (fragments) on lane & 31, half on lane >> 5
+    const int nqb = T / (NW * 64);
+    const int nb = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qd = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
+    }
+    const int qblk = logical % nqb, bh = logical / nqb;
+    const int b = bh / H, head = bh - b * H;
+    const int q0w = qblk * (NW * 64) + wave * 64;            // first query of this wave; strand X: q0w + 32 X + [0, 32)
+    const int nt = Tk >> 6;
+
+    // constant parts of the LDS image: rows D .. 32 DT - 1 of every slot's V^T (row D = ones), and [1 0 0 0 0 0 0 0] / zeros for
+    // the fold slot of K
+    char* const cst = smem + NSLOT * SLOT;
+    if (tid < 2) {
+        h8 v = (h8)(half_t)0;
+        if (tid == 0) v[0] = (half_t)1;
+        *(h8*)(cst + tid * 16) = v;
+    }
+    for (int i = tid; i < NSLOT * (DT * 32 - D) * 8; i += NW * 64) {
+        const int sl_i = i / ((DT * 32 - D) * 8), rem = i - sl_i * ((DT * 32 - D) * 8), row = D + rem / 8, pc = rem & 7;
+        *(h8*)(smem + sl_i * SLOT + KBYTES + row * 128 + pc * 16) = row == D ? (h8)(half_t)1 : (h8)(half_t)0;
+    }
+
+    // ---- LDS-DMA plan of this wave (see the kernel above).  K row order inside a 32-key sub-tile: LDS row rho = 8 a + 4 b + c
+    // holds key 16 (a >> 1) + 8 b + 4 (a & 1) + c: lane half b of the B operand of k-step s2 = a >> 1 holds the probabilities of
+    // LDS rows {8 (2 s2) + 4 b + c, 8 (2 s2 + 1) + 4 b + c}, i.e. of keys 16 s2 + 8 b + [0, 8)
+    const half_t* Kb = K + (size_t)b * Tk * ldk + head * D;
+    const half_t* Vb = Vt + ((size_t)b * H + head) * D * ldvt;
+    unsigned voff[NI], ldst[NI];
+    bool isk[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        int j = wave + NW * u;
+        if (j >= NDMA) j -= NW;
+        isk[u] = j < KBYTES / 1024;
+        ldst[u] = (unsigned)j * 1024u;
+        if (isk[u]) {
+            const int L = 64 * j + lane, rp = L / DC, c = L - rp * DC;
+            const int rho = rp & 31, a = rho >> 3;
+            const int key = (rp & 32) + 16 * (a >> 1) + 8 * ((rho >> 2) & 1) + 4 * (a & 1) + (rho & 3);
+            voff[u] = (unsigned)(key * ldk + c * 8) * 2u;
+        } else {
+            const int L = 64 * (j - KBYTES / 1024) + lane, d = L >> 3, x = L & 7;
+            voff[u] = (unsigned)(d * ldvt + ((x ^ ((d >> 1) & 7)) * 8)) * 2u;
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+    auto issue = [&](int t, auto slotc) {                    // tile t -> slot t % NSLOT
+        const char* kb = (const char*)(Kb + (size_t)t * 64 * ldk);
+        const char* vb = (const char*)(Vb + t * 64);
+        const unsigned base = lds0 + (unsigned)decltype(slotc)::value * SLOT;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) att_dma16(voff[u], isk[u] ? kb : vb, base + ldst[u]);
+    };
+    issue(0, std::integral_constant<int, 0>{});
+    if (nt > 1) issue(1, std::integral_constant<int, 1>{});
+
+    // ---- Q^T fragments (B operand of K Q^T), pre-scaled; slot D will carry -max
+    h8 qf[2][NKS];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const int c = 16 * s + 8 * h;
+            qf[X][s] = (h8)(half_t)0;
+            if (c < D) qf[X][s] = *(const h8*)(Q + ((size_t)b * T + q0w + 32 * X + n32) * ldq + head * D + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[X][s][e] = (half_t)((float)qf[X][s][e] * sl2e);
+        }
+    f32x16 oacc[2][DT];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[X][t][r] = 0.f;
+    float m_run[2] = {0.f, 0.f};
+
+    // ---- fragment addresses inside a slot.  K: row (32 sub + n32), piece 2 s + h -> immediate offsets 32 KROW sub + 32 s;
+    // pieces >= DC are the constants.  V^T: row 32 t + n32, source piece 4 sub + 2 s2 + h at position (that) ^ ((n32 >> 1) & 7).
+    const int k_lane = n32 * KROW + h * 16;
+    int v_lane[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) v_lane[sub][s2] = KBYTES + n32 * 128 + (((4 * sub + 2 * s2 + h) ^ ((n32 >> 1) & 7)) * 16);
+    const char* const c_one = cst, *const c_zero = cst + 16;
+
+    f32x16 sacc[2][2];
+    h8 kf[2][NKS], vf[DT][2][2], pf[2][2][2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define ATT_SB() __builtin_amdgcn_sched_barrier(0)
+    auto rd_k = [&](const char* sl, int sub, int s) {
+        const int ci0 = 2 * s;                               // piece index of lane half 0; half 1 reads ci0 + 1
+        const char* p = sl + k_lane + sub * 32 * KROW + s * 32;
+        if (ci0 + 1 >= DC) {                                 // some lanes read a constant piece
+            const char* cp0 = ci0 < DC ? p : (ci0 == DC ? c_one : c_zero);
+            const char* cp1 = ci0 + 1 == DC ? c_one : c_zero;
+            p = h ? cp1 : cp0;
+        }
+        kf[sub][s] = *(const h8*)p;
+    };
+    auto rd_v = [&](const char* sl, int t, int sub, int s2) { vf[t][sub][s2] = *(const h8*)(sl + v_lane[sub][s2] + t * 32 * 128); };
+    auto qk = [&](int X, int sub, int s) {
+        if constexpr ((ABL & 32) != 0) { if (s == 0) asm volatile("" : "=v"(sacc[X][sub])); return; }
+        sacc[X][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sub][s], qf[X][s], s == 0 ? zero16 : sacc[X][sub], 0, 0, 0);
+    };
+    auto pv = [&](int X, int sub, int t, int s2) {
+        if constexpr ((ABL & 16) != 0) { asm volatile("" : "+v"(oacc[X][t]) : "v"(vf[t][sub][s2]), "v"(pf[X][sub][s2])); return; }
+        oacc[X][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t][sub][s2], pf[X][sub][s2], oacc[X][t], 0, 0, 0);
+    };
+    auto max_part = [&](int X, int sub, float mx) {          // 8 v_max3 over one sub-tile's 16 scores of this lane
+        if constexpr ((ABL & 2) != 0) return mx;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[X][sub][r]), sacc[X][sub][r + 1]);
+        return mx;
+    };
+    auto max_cross = [&](float mx) {                         // the other key half of the same query: lane ^ 32 (asm: see above)
+        float lo = mx, hi = mx;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        return fmaxf(lo, hi);
+    };
+    auto decide = [&](int X, float mx, bool first) {
+        if constexpr ((ABL & 2) != 0) return;
+        if (first || !__all(mx <= ATT_THR)) {
+            const float m_new = first ? mx : m_run[X] + fmaxf(mx, 0.f);
+            const float m_hat = (float)(half_t)m_new;        // exactly what Q[q][D] can hold
+            const float delta = m_run[X] - m_hat;
+            m_run[X] = m_hat;
+            if (!first) {
+                const float alpha = __builtin_amdgcn_exp2f(delta);
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[X][t][r] *= alpha;
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[X][sub][r] += delta;   // this tile was taken against the old offset
+            if (h == PH) qf[X][PS][0] = (half_t)(-m_hat);
+        }
+    };
+    auto expo = [&](int X, int sub, int r0, int r1) {
+#pragma unroll
+        for (int r = r0; r < r1; ++r) sacc[X][sub][r] = (ABL & 1) ? sacc[X][sub][r] : __builtin_amdgcn_exp2f(sacc[X][sub][r]);
+    };
+    auto pack = [&](int X, int sub) {                        // fp16 probabilities: registers 8 s2 .. 8 s2 + 7 are k-step s2's B operand
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[X][sub][s2][e] = (half_t)sacc[X][sub][8 * s2 + e];
+    };
+    constexpr int NPV = DT * 2;                              // V^T P^T MFMAs per 32-key sub-tile and strand
+    auto tile = [&](int kt, auto slotc) {
+        constexpr int slot = decltype(slotc)::value;
+        if (!(ABL & 4) && kt + 1 < nt) att_wait_vmcnt<NI>(); else att_wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 4) && kt + 2 < nt) issue(kt + 2, std::integral_constant<int, (slot + 2) % NSLOT>{});
+        const char* sl = smem + slot * SLOT;
+        const bool first = kt == 0;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) rd_k(sl, sub, s);
+        ATT_SB();
+        // (b) K Q^T of strand A; the V^T fragments of the first 32 keys are requested between its MFMAs
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const int i = sub * NKS + s;
+                qk(0, sub, s);
+                if (i < NPV) rd_v(sl, i / 2, 0, i & 1);
+                ATT_SB();
+            }
+        // (c) K Q^T of strand B  |  strand A: maximum, decision, exp and pack of its first 32 keys
+        float mx = sacc[0][0][0];                            // (sub-tile 0 first: its MFMAs retired three MFMAs ago)
+        qk(1, 0, 0); mx = max_part(0, 0, mx); ATT_SB();
+        qk(1, 0, 1); mx = max_part(0, 1, mx); ATT_SB();
+        qk(1, 0, 2 % NKS); mx = max_cross(mx); ATT_SB();
+#pragma unroll
+        for (int s = 3; s < NKS; ++s) { qk(1, 0, s); ATT_SB(); }
+        decide(0, mx, first);
+        ATT_SB();
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            qk(1, 1, s);
+            expo(0, 0, 16 * s / NKS, 16 * (s + 1) / NKS);
+            if (s < NPV) rd_v(sl, s / 2, 1, s & 1);          // ... and the V^T fragments of the second 32 keys
+            ATT_SB();
+        }
+#pragma unroll
+        for (int i = NKS; i < NPV; ++i) rd_v(sl, i / 2, 1, i & 1);
+        pack(0, 0);
+        ATT_SB();
+        // (d) V^T P^T of strand A, first 32 keys  |  strand A: exp of its second 32 keys; strand B: maximum
+        float mxb = sacc[1][0][0];
+#pragma unroll
+        for (int i = 0; i < NPV; ++i) {
+            pv(0, 0, i / 2, i & 1);
+            expo(0, 1, 16 * i / NPV, 16 * (i + 1) / NPV);
+            if (i == NPV - 3) mxb = max_part(1, 0, mxb);
+            if (i == NPV - 2) mxb = max_part(1, 1, mxb);
+            if (i == NPV - 1) mxb = max_cross(mxb);
+            ATT_SB();
+        }
+        pack(0, 1);
+        ATT_SB();
+        decide(1, mxb, first);
+        ATT_SB();
+        // (e) V^T P^T of strand A, second 32 keys  |  strand B: exp and pack of its first 32 keys
+#pragma unroll
+        for (int i = 0; i < NPV; ++i) {
+            pv(0, 1, i / 2, i & 1);
+            expo(1, 0, 16 * i / NPV, 16 * (i + 1) / NPV);
+            ATT_SB();
+        }
+        pack(1, 0);
+        ATT_SB();
+        // (f) V^T P^T of strand B, first 32 keys  |  strand B: exp and pack of its second 32 keys
+#pragma unroll
+        for (int i = 0; i < NPV; ++i) {
+            pv(1, 0, i / 2, i & 1);
+            expo(1, 1, 16 * i / NPV, 16 * (i + 1) / NPV);
+            ATT_SB();
+        }
+        pack(1, 1);
+        ATT_SB();
+        // (g) V^T P^T of strand B, second 32 keys
+#pragma unroll
+        for (int i = 0; i < NPV; ++i) pv(1, 1, i / 2, i & 1);
+        ATT_SB();
+    };
+    for (int kt = 0; kt < nt; kt += NSLOT) {
+        tile(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < nt) tile(kt + 1, std::integral_constant<int, 1>{});
+        if (kt + 2 < nt) tile(kt + 2, std::integral_constant<int, 2>{});
+    }
+#undef ATT_SB
+
+    // ---- O = O^T / l: row D of O^T lives in tile D / 32, register ((D % 32) & 3) + 4 ((D % 32) >> 3) of the half with 4 h == (D % 32) & 4
+    constexpr int rr = D % 32, reg = (rr & 3) + 4 * (rr >> 3), owner_half = (rr >> 2) & 1;
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const float mine = oacc[X][D / 32][reg];
+        const float other = __shfl_xor(mine, 32);
+        const float inv = 1.0f / (h == owner_half ? mine : other);
+        half_t* op = O + ((size_t)b * T + q0w + 32 * X + n32) * ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = t * 32 + 8 * g4 + 4 * h;
+                if (dd < D) {
+                    const h4 o4 = {(half_t)(oacc[X][t][4 * g4] * inv), (half_t)(oacc[X][t][4 * g4 + 1] * inv),
+                                   (half_t)(oacc[X][t][4 * g4 + 2] * inv), (half_t)(oacc[X][t][4 * g4 + 3] * inv)};
+                    *(h4*)(op + dd) = o4;
+                }
+            }
+    }
+}
+
 int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* Vt, int ldvt, half_t* O,
                      int ldo, int B, int H, int T, int Tk, int d, int q_prescaled, hipStream_t s) {
     if (B <= 0 || H <= 0 || T <= 0 || Tk <= 0) return FGDM_ERR_ARG;
@@ -1240,23 +1533,26 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
     // long self-attention: the eight-wave ping-pong kernel (256 queries per workgroup); FGDM_ATTN_PP=0 switches it off (A/B)
     static const bool pp_on = !(getenv("FGDM_ATTN_PP") && atoi(getenv("FGDM_ATTN_PP")) == 0);
     // ... and the two-strand kernel where its shape conditions hold (FGDM_ATTN_DQ: 0 = off, 1 = plain, 2 = rotated tail)
-    static const int dq = getenv("FGDM_ATTN_DQ") ? atoi(getenv("FGDM_ATTN_DQ")) : 0;
-    const int dq_nw = dq == 2 ? 8 : 4;       // 1 = four waves per workgroup, 2 = eight
-    if (dq > 0 && d == 40 && T % (64 * dq_nw) == 0 && Tk % 64 == 0 && Tk >= 128 && (size_t)64 * ldk * 2 < (1u << 31) &&
+    // ... and the two-strand kernels where their shape conditions hold.  FGDM_ATTN_DQ: 0 = off, 1 = 16-wide V^T P^T (the faster one
+    // on random operands: 756 vs 733 TF/s at B32 T4096), 3 = 32-wide V^T P^T (default: the faster one inside the network, where the
+    // activations toggle less and the chip holds its clock: attention family 357 vs 362 ms per sampling pass, 421 before)
+    static const int dq = getenv("FGDM_ATTN_DQ") ? atoi(getenv("FGDM_ATTN_DQ")) : 3;
+    if (dq > 0 && d == 40 && T % 256 == 0 && Tk % 64 == 0 && Tk >= 128 && (size_t)64 * ldk * 2 < (1u << 31) &&
         (size_t)d * ldvt * 2 < (1u << 31)) {
-        const dim3 gridq((T / (64 * dq_nw)) * H * B), blockq(64 * dq_nw);
-        static const int abl = getenv("FGDM_ATTN_ABL") ? atoi(getenv("FGDM_ATTN_ABL")) : 0;
-        if (abl && dq_nw == 4) {
-            switch (abl) {
-#define ATT_ABL_CASE(v) case v: FGDM_LAUNCH((attn_dq_kernel<40, 4, v>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
+        const dim3 gridq((T / 256) * H * B), blockq(256);
+        static const int abl = getenv("FGDM_ATTN_ABL") ? atoi(getenv("FGDM_ATTN_ABL")) : 0;     // tools/bench_attention.py only
+        if (abl) {
+            switch (abl + (dq == 3 ? 1000 : 0)) {
+#define ATT_ABL_CASE(v) case v: FGDM_LAUNCH((attn_dq_kernel<40, 4, v>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break; \
+                        case 1000 + v: FGDM_LAUNCH((attn_dq32_kernel<40, 4, v>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e); break;
                 ATT_ABL_CASE(1) ATT_ABL_CASE(2) ATT_ABL_CASE(3) ATT_ABL_CASE(4) ATT_ABL_CASE(16) ATT_ABL_CASE(32) ATT_ABL_CASE(48) ATT_ABL_CASE(51) ATT_ABL_CASE(7)
 #undef ATT_ABL_CASE
                 default: return FGDM_ERR_ARG;
             }
             return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
         }
-        if (dq_nw == 4) FGDM_LAUNCH((attn_dq_kernel<40, 4>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
-        else FGDM_LAUNCH((attn_dq_kernel<40, 8>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        if (dq == 1) FGDM_LAUNCH((attn_dq_kernel<40, 4>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        else FGDM_LAUNCH((attn_dq32_kernel<40, 4>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
         return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
     }
     if (pp_on && T >= 256 && Tk >= 256 && (d == 40 || d == 80)) {

@@ -3,6 +3,7 @@
 #   bash tools/profile_round.sh r02
 # 1. rocprofv3 --kernel-trace --stats of the default bench command            -> gpurun_out/<tag>_kernel_stats.csv (+ bench JSON)
 # 2. PMC FETCH_SIZE and WRITE_SIZE in SEPARATE passes (MI355X guide, HBM)     -> gpurun_out/<tag>_pmc_traffic.json
+# 3. SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE in one more pass       -> gpurun_out/<tag>_mfma_busy.txt
 # Copy the summaries into profiles/ afterwards (gpurun_out/ is scratch).
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -19,4 +20,9 @@ done
 python3 tools/pmc_summary.py $(find gpurun_out/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) \
     $(find gpurun_out/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) gpurun_out/${TAG}_pmc_traffic.json > /dev/null
 rm -rf gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_mfma -o p -- python3 bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-first-stage \
+    > /dev/null 2>> gpurun_out/${TAG}_prof.log || exit 1
+python3 tools/pmc_mfma.py $(find gpurun_out/${TAG}_pmc_mfma -name '*counter_collection.csv' | head -1) gpurun_out/${TAG}_kernel_stats.csv > gpurun_out/${TAG}_mfma_busy.txt
+rm -rf gpurun_out/${TAG}_pmc_mfma
 head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-160
+cat gpurun_out/${TAG}_mfma_busy.txt
