@@ -70,6 +70,7 @@ SIGNATURES = {
     'fgdm_profile_begin': (_i, [_p, _i]),
     'fgdm_profile_end': (_i, [_p, C.POINTER(C.c_double)]),
     'fgdm_workspace_stats': (_i, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    'fgdm_launch_stats': (_i, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     'fgdm_op_conv2d': (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
     'fgdm_op_linear': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     'fgdm_debug_force_igemm_cfg': (_i, [_i]),
@@ -99,10 +100,13 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f'{LIB_PATH} not found: build it with `python -m fgdm_amd.build` '
+    # FGDM_LIB: another BUILD of the same library (tools/ab_lib.sh alternates two builds on one box without touching the in-tree
+    # file); it must export every symbol like the in-tree one, and there is still no fallback
+    path = os.environ.get('FGDM_LIB') or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f'{path} not found: build it with `python -m fgdm_amd.build` '
                            '(the HIP engine is mandatory, there is no CPU fallback)')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(os.path.abspath(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res

@@ -175,13 +175,15 @@ int ancestral_step(const float* x, const float* eps, float sqrt_recip, float sqr
 // ---------------------------------------------------------------- deferred launches (twin-layer grouped launches)
 // While the engine RECORDS (engine.hip: apply_model with FGDM_PAIR_LAUNCH), nothing is enqueued: every launch site goes through
 // FGDM_LAUNCH, which then stores a closure (arguments by value) in the engine's list instead; the engine replays the lists of the
-// UNet encoder and of a ControlNet in lockstep and fuses launches of the same pipelined-GEMM instantiation and grid into ONE
-// grouped launch (igemm2.hip: igemm2_pair_kernel; blockIdx.y selects the argument set), so that the half-empty grids of the
-// 16x16 / 8x8 levels fill the chip.  Each net's launches keep their order, so the results do not change by a bit.
+// UNet encoder and of the ControlNets in lockstep and fuses launches of the same pipelined-GEMM instantiation and grid into ONE
+// grouped launch (igemm2.hip: igemm2_group_kernel; blockIdx.y selects the argument set: the UNet plus up to four ControlNets),
+// so that the half-empty grids of the 16x16 / 8x8 levels fill the chip.  Each net's launches keep their order, so the results do
+// not change by a bit.
 #include <functional>
-typedef int (*IgemmPairFn)(const IgemmArgs& a0, const IgemmArgs& a1, unsigned grid_x, hipStream_t s);
+#define FGDM_MAX_GROUP 5
+typedef int (*IgemmGroupFn)(const IgemmArgs* const* a, int n, unsigned grid_x, hipStream_t s);
 bool fgdm_recording();
-void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key = nullptr, IgemmPairFn pair = nullptr,
+void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key = nullptr, IgemmGroupFn pair = nullptr,
                  const IgemmArgs* ia = nullptr, unsigned grid_x = 0);
 #define FGDM_LAUNCH(kernel, grid, block, smem, stream, ...)                                                                  \
     do {                                                                                                                     \

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -185,7 +186,7 @@ struct RecOp {
     enum Kind { RUN, PROF_BEGIN, PROF_END } kind = RUN;
     std::function<int(hipStream_t)> run;
     const void* pair_key = nullptr;      // RUN of a pipelined-GEMM instantiation that has a two-problem twin
-    IgemmPairFn pair = nullptr;
+    IgemmGroupFn pair = nullptr;
     IgemmArgs ia{};
     unsigned grid_x = 0;
     int cls = 0;                         // PROF_BEGIN
@@ -251,7 +252,7 @@ struct Prof {
 }  // namespace
 
 bool fgdm_recording() { return g_rec != nullptr; }
-void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key, IgemmPairFn pair, const IgemmArgs* ia, unsigned grid_x) {
+void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key, IgemmGroupFn pair, const IgemmArgs* ia, unsigned grid_x) {
     RecOp o;
     o.run = std::move(run);
     o.pair_key = pair_key; o.pair = pair; o.grid_x = grid_x;
@@ -288,7 +289,11 @@ struct fgdm_engine {
     // FGDM_TWIN_STREAMS=1: the ControlNets run on a second stream (own arena: an arena's block reuse relies on stream order) next
     // to the UNet encoder + middle block, which they do not depend on (cldm.py:40,46: the UNet takes `control` only after its middle
     // block); their zero-convs are applied on the main stream behind a join event
-    Arena arena2, arena3;       // the ControlNets' workspaces (second stream / recorded walks); arena3: see apply_model, grouped launches
+    // the ControlNets' workspaces: ONE ARENA PER ControlNet (round 4).  A recorded walk hands blocks out and takes them back at
+    // RECORD time, so two walks recorded from one arena share blocks; replayed INTERLEAVED (grouped launches) they would overwrite
+    // each other (three ControlNets at full size gave non-finite latents in round 3, fixed then by a hand-derived two-arena rule).
+    // With an arena of its own every walk may be replayed next to any other.  cn_arena[0] also serves the second stream.
+    std::vector<std::unique_ptr<Arena>> cn_arena;
     Arena* ar = &arena;           // arena of the stream being enqueued
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -296,7 +301,7 @@ struct fgdm_engine {
     // FGDM_PAIR_LAUNCH (default on): the UNet encoder + middle block and the ControlNets are RECORDED (common.h, "deferred
     // launches") and replayed in lockstep on the one stream, twin GEMM launches fused into grouped launches (replay_zip)
     bool pair_launch = true;
-    long paired_launches = 0, replayed_launches = 0;
+    long paired_launches = 0, replayed_launches = 0, paired_problems = 0;      // fused launches; all replayed launches; problems in fused launches
     struct Deferred { const GemmW* w; Tensor src; int idx; float scale; Arena* owner; };
     Prof prof;
 
@@ -1490,43 +1495,62 @@ struct fgdm_engine {
         for (size_t k = u.first; k <= u.last; ++k) CHK(run_op(v[k]));
         return FGDM_OK;
     }
-    // Two recorded walks, replayed in lockstep: each list keeps its order (the nets are independent of each other); a fusable GEMM
-    // launch of A is fused with the next launch of B of the same instantiation and grid found within a short look-ahead
-    int replay_zip(std::vector<RecOp>& A, std::vector<RecOp>& B) {
-        size_t i = 0, j = 0;
+    // Recorded walks, replayed in lockstep (round 4: any number of them, one grouped launch for the UNet and ALL its ControlNets):
+    // each list keeps its order (the nets are independent of each other); a fusable GEMM launch of the leading list is fused with
+    // the next launch of the same instantiation and grid that each other list holds within a short look-ahead.  When the leading
+    // list runs out, the next one leads.
+    int replay_group(std::vector<std::vector<RecOp>*> L) {
         constexpr int LOOK = 24;
-        while (i < A.size()) {
-            const Unit ua = unit_at(A, i);
-            long partner = -1;
-            Unit ub{0, 0, -1};
-            if (ua.launch >= 0) {
-                size_t jj = j;
-                for (int d = 0; d < LOOK && jj < B.size(); ++d) {
-                    const Unit u = unit_at(B, jj);
-                    if (u.launch >= 0 && B[u.launch].pair_key == A[ua.launch].pair_key && B[u.launch].grid_x == A[ua.launch].grid_x) {
-                        partner = (long)jj; ub = u;
-                        break;
-                    }
-                    jj = u.last + 1;
-                }
-            }
-            if (partner < 0) { CHK(run_unit(A, ua)); i = ua.last + 1; continue; }
-            while (j < (size_t)partner) { const Unit u = unit_at(B, j); CHK(run_unit(B, u)); j = u.last + 1; }
-            // fused: one bracket (both problems' work), one launch
-            RecOp& la = A[ua.launch];
-            RecOp& lb = B[ub.launch];
-            const bool ba = ua.first != ua.last, bb = ub.first != ub.last;
-            if (ba || bb) {
-                RecOp& pa = ba ? A[ua.first] : B[ub.first];
-                prof.begin(pa.cls, s, (ba ? A[ua.first].w : 0.0) + (bb ? B[ub.first].w : 0.0), pa.tag,
-                           (ba ? A[ua.first].bytes : 0.0) + (bb ? B[ub.first].bytes : 0.0));
-            }
-            CHK(la.pair(la.ia, lb.ia, la.grid_x, s));
-            if (ba || bb) prof.end(s);
-            ++paired_launches; replayed_launches += 1;
-            i = ua.last + 1; j = ub.last + 1;
+        while (L.size() > FGDM_MAX_GROUP) {      // (more walks than a grouped launch takes: the surplus replays on its own)
+            std::vector<RecOp>& v = *L.back();
+            for (size_t i = 0; i < v.size();) { const Unit u = unit_at(v, i); CHK(run_unit(v, u)); i = u.last + 1; }
+            L.pop_back();
         }
-        while (j < B.size()) { const Unit u = unit_at(B, j); CHK(run_unit(B, u)); j = u.last + 1; }
+        std::vector<size_t> at(L.size(), 0);
+        for (size_t lead = 0; lead < L.size(); ++lead) {
+            std::vector<RecOp>& A = *L[lead];
+            while (at[lead] < A.size()) {
+                const Unit ua = unit_at(A, at[lead]);
+                size_t who[FGDM_MAX_GROUP];
+                Unit un[FGDM_MAX_GROUP];
+                int n = 0;
+                if (ua.launch >= 0) {
+                    who[n] = lead; un[n++] = ua;
+                    for (size_t m = lead + 1; m < L.size(); ++m) {
+                        std::vector<RecOp>& B = *L[m];
+                        size_t jj = at[m];
+                        for (int d = 0; d < LOOK && jj < B.size(); ++d) {
+                            const Unit u = unit_at(B, jj);
+                            if (u.launch >= 0 && B[u.launch].pair_key == A[ua.launch].pair_key && B[u.launch].grid_x == A[ua.launch].grid_x) {
+                                who[n] = m; un[n++] = u;
+                                break;
+                            }
+                            jj = u.last + 1;
+                        }
+                    }
+                }
+                if (n < 2) { CHK(run_unit(A, ua)); at[lead] = ua.last + 1; continue; }
+                // everything the partners hold in front of their member of the group runs first, in their own order
+                for (int k = 1; k < n; ++k) {
+                    std::vector<RecOp>& B = *L[who[k]];
+                    while (at[who[k]] < un[k].first) { const Unit u = unit_at(B, at[who[k]]); CHK(run_unit(B, u)); at[who[k]] = u.last + 1; }
+                }
+                // fused: one bracket (all the problems' work), one launch
+                const IgemmArgs* av[FGDM_MAX_GROUP];
+                double w = 0.0, bytes = 0.0;
+                const RecOp* br = nullptr;
+                for (int k = 0; k < n; ++k) {
+                    std::vector<RecOp>& B = *L[who[k]];
+                    av[k] = &B[un[k].launch].ia;
+                    if (un[k].first != un[k].last) { w += B[un[k].first].w; bytes += B[un[k].first].bytes; if (!br) br = &B[un[k].first]; }
+                }
+                if (br) prof.begin(br->cls, s, w, br->tag, bytes);
+                CHK(A[ua.launch].pair(av, n, A[ua.launch].grid_x, s));
+                if (br) prof.end(s);
+                ++paired_launches; ++replayed_launches; paired_problems += n;
+                for (int k = 0; k < n; ++k) at[who[k]] = un[k].last + 1;
+            }
+        }
         return FGDM_OK;
     }
 
@@ -1659,14 +1683,12 @@ struct fgdm_engine {
         struct RecGuard { ~RecGuard() { g_rec = nullptr; igemm_set_pair_hint(1); } } rec_guard;   // whatever path leaves: recording ends
         if (paired) {
             static const bool fat = !(getenv("FGDM_PAIR_FAT_TILES") && atoi(getenv("FGDM_PAIR_FAT_TILES")) == 0);       // A/B knob
-            if (fat) igemm_set_pair_hint(2);
+            // FGDM_GROUP_MAX: 2 = round 3's pairwise replay (UNet + first ControlNet, the others two by two): the A/B knob
+            static const int group_max = getenv("FGDM_GROUP_MAX") ? std::max(2, std::min(FGDM_MAX_GROUP, atoi(getenv("FGDM_GROUP_MAX")))) : FGDM_MAX_GROUP;
+            if (fat) igemm_set_pair_hint(std::min<int>(group_max, 1 + (int)cns.size()));
             int rc = FGDM_OK;
             for (size_t c = 0; c < cns.size() && rc == FGDM_OK; ++c) {
-                // A recorded walk hands blocks out and takes them back at RECORD time, so two walks recorded one after the other from
-                // one arena share blocks -- harmless when they are also replayed one after the other (ControlNet 0, zipped with the
-                // UNet, is done before 1 starts), fatal when they are replayed INTERLEAVED: the pairs (1, 2), (3, 4) ... take their
-                // second member's workspace from another arena (three ControlNets at full size gave non-finite latents without it)
-                ar = (c >= 2 && c % 2 == 0) ? &arena3 : &arena2;
+                ar = cn_arena[c].get();           // an arena per walk: see cn_arena
                 g_rec = &rec_cn[c];
                 rc = controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, nullptr, nullptr, false, nullptr, 0, pairs,
                                     &deferred);
@@ -1679,7 +1701,7 @@ struct fgdm_engine {
         if (twin) {
             if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, ev_fork, 0) != hipSuccess) return fail(FGDM_ERR_HIP, "stream fork");
             hipStream_t main_s = s;
-            s = s2; ar = &arena2;
+            s = s2; ar = cn_arena[0].get();
             int rc = FGDM_OK;
             for (size_t c = 0; c < cns.size() && rc == FGDM_OK; ++c)
                 rc = controlnet_fwd(cns[c], x4, t, tf, ctx16, scales ? scales + 13 * c : nullptr, nullptr, nullptr, false, nullptr, 0, pairs,
@@ -1730,12 +1752,14 @@ struct fgdm_engine {
         if (paired) {
             g_rec = nullptr;
             igemm_set_pair_hint(1);
-            // UNet with the first ControlNet, further ControlNets with each other
-            CHK(replay_zip(rec_un, rec_cn[0]));
-            for (size_t c = 1; c < rec_cn.size(); c += 2) {
-                std::vector<RecOp> none;
-                CHK(replay_zip(rec_cn[c], c + 1 < rec_cn.size() ? rec_cn[c + 1] : none));
+            static const int group_max = getenv("FGDM_GROUP_MAX") ? std::max(2, std::min(FGDM_MAX_GROUP, atoi(getenv("FGDM_GROUP_MAX")))) : FGDM_MAX_GROUP;
+            // the UNet and ALL its ControlNets in one lockstep replay (FGDM_GROUP_MAX=2: pairwise, as in round 3)
+            std::vector<std::vector<RecOp>*> lists{&rec_un};
+            for (size_t c = 0; c < rec_cn.size(); ++c) {
+                if ((int)lists.size() == group_max) { CHK(replay_group(lists)); lists.clear(); }
+                lists.push_back(&rec_cn[c]);
             }
+            CHK(replay_group(lists));
         }
         if (twin || paired) {
             if (twin && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return fail(FGDM_ERR_HIP, "stream join");
@@ -1976,15 +2000,13 @@ template <typename F> static int scoped_call(fgdm_engine* e, void* stream, F f) 
     e->s = as_stream(stream);
     e->ar = &e->arena;
     e->arena.begin_scope();
-    e->arena2.begin_scope();
-    e->arena3.begin_scope();
+    for (auto& a : e->cn_arena) a->begin_scope();
     const int rc = f();
     e->s = as_stream(stream);
     e->ar = &e->arena;
     if (rc != FGDM_OK && e->s2) (void)hipStreamSynchronize(e->s2);      // nothing of the second stream may outlive its blocks
     e->arena.end_scope(rc != FGDM_OK);
-    e->arena2.end_scope(rc != FGDM_OK);
-    e->arena3.end_scope(rc != FGDM_OK);
+    for (auto& a : e->cn_arena) a->end_scope(rc != FGDM_OK);
     return rc;
 }
 
@@ -2015,7 +2037,11 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
             delete e;
             return FGDM_ERR_HIP;
         }
-        if (e->cfg.workspace_bytes > 0) e->arena2.slab_bytes = (size_t)e->cfg.workspace_bytes;
+    }
+    // one workspace arena per ControlNet, sized like the main one (the configured slab size applies to all of them)
+    for (size_t c = 0; c < e->cns.size(); ++c) {
+        e->cn_arena.emplace_back(new Arena());
+        if (e->cfg.workspace_bytes > 0) e->cn_arena.back()->slab_bytes = (size_t)e->cfg.workspace_bytes;
     }
     *out = e;
     return FGDM_OK;
@@ -2030,7 +2056,7 @@ void fgdm_destroy(fgdm_engine* e) {
     e->drop_context();
     e->drop_adapter_conds();
     if (getenv("FGDM_PAIR_DEBUG") && e->replayed_launches)
-        fprintf(stderr, "[fgdm] grouped twin launches: %ld of %ld replayed launches were fused pairs\n", e->paired_launches, e->replayed_launches);
+        fprintf(stderr, "[fgdm] grouped twin launches: %ld of %ld replayed launches were fused (%ld problems)\n", e->paired_launches, e->replayed_launches, e->paired_problems);
     if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -2153,10 +2179,23 @@ int fgdm_profile_end(fgdm_engine* e, double* out) {
 }
 int fgdm_workspace_stats(fgdm_engine* e, int64_t* peak_bytes, int64_t* reserved_bytes) {
     if (!e || !peak_bytes || !reserved_bytes) return FGDM_ERR_ARG;
-    *peak_bytes = (int64_t)e->arena.peak;
-    size_t r = 0;
+    // all arenas: the main one and the ControlNets' (with grouped launches every ControlNet activation lives in those)
+    size_t pk = e->arena.peak, r = 0;
     for (auto& sl : e->arena.slabs) for (auto& b : sl) r += b.sz;
+    for (auto& a : e->cn_arena) {
+        pk += a->peak;
+        for (auto& sl : a->slabs) for (auto& b : sl) r += b.sz;
+    }
+    *peak_bytes = (int64_t)pk;
     *reserved_bytes = (int64_t)r;
+    return FGDM_OK;
+}
+
+int fgdm_launch_stats(fgdm_engine* e, int64_t* replayed_launches, int64_t* fused_launches, int64_t* fused_problems) {
+    if (!e || !replayed_launches || !fused_launches || !fused_problems) return FGDM_ERR_ARG;
+    *replayed_launches = (int64_t)e->replayed_launches;
+    *fused_launches = (int64_t)e->paired_launches;
+    *fused_problems = (int64_t)e->paired_problems;
     return FGDM_OK;
 }
 

@@ -358,6 +358,12 @@ class Engine:
         self._check(self.lib.fgdm_workspace_stats(self.h, C.byref(a), C.byref(b)), 'fgdm_workspace_stats')
         return dict(peak_bytes=a.value, reserved_bytes=b.value)
 
+    def launch_stats(self):
+        """Grouped twin launches since the engine was created: replayed launches, fused launches, problems in fused launches."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.fgdm_launch_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), 'fgdm_launch_stats')
+        return dict(replayed_launches=a.value, fused_launches=b.value, fused_problems=c.value)
+
     def control_shapes(self, B, H, W):
         c = self.config
         mc = c.model_channels

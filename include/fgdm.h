@@ -185,6 +185,10 @@ int fgdm_profile_begin(fgdm_engine* e, int stride /* bracket every stride-th lau
 int fgdm_profile_end(fgdm_engine* e, double* out);
 /* Activation workspace: peak bytes in use during the last calls, and bytes reserved from HBM. */
 int fgdm_workspace_stats(fgdm_engine* e, int64_t* peak_bytes, int64_t* reserved_bytes);
+/* Grouped twin launches (the UNet encoder and the ControlNets of ControlLDM.apply_model, controlnet/cldm/cldm.py:836-849, share every
+ * layer shape): launches replayed from recorded walks since fgdm_create, how many of them were fused launches, and how many
+ * problems those carried.  Diagnostic: the tests assert that the fused kernel really ran. */
+int fgdm_launch_stats(fgdm_engine* e, int64_t* replayed_launches, int64_t* fused_launches, int64_t* fused_problems);
 
 /* Per-kernel entry points used by the parity tests (tests/test_gpu_ops.py); weights given in the reference's
  * native layouts (fp32, [Cout,Cin,kh,kw] / [N,K]) and packed on the fly.  Activations fp16 NHWC. */

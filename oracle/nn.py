@@ -42,7 +42,7 @@ def _gn(x, p, name, eps):
 
 def _ln(x, p, name):
     # nn.LayerNorm: fp32 output under autocast whatever the input dtype; the engine stores it as fp16
-    return st(F.layer_norm(x, x.shape[-1:], p[name + '.weight'], p[name + '.bias'], 1e-5))
+    return st(F.layer_norm(x, x.shape[-1:], p[name + '.weight'], p[name + '.bias'], 1e-5), 'norm')
 
 
 # Test-only knob (tests/test_oracle_autocast.py): evaluate every convolution on a channels-last copy of its input.
@@ -63,25 +63,25 @@ def _lin(x, p, name, bias=True, wscale=None):
 def time_embed(p, prefix, t, mc):
     # engine: timestep_embed writes fp16; time_embed.0 and .2 carry SiLU in their epilogues (the only use of `emb`
     # is SiLU(emb) in every ResBlock's emb_layers, openaimodel.py:238-244), so `emb` itself is never stored
-    e = st(timestep_embedding(t, mc))
+    e = st(timestep_embedding(t, mc), 'misc')
     e = _lin(e, p, prefix + 'time_embed.0')
-    e = st(F.silu(e))
+    e = st(F.silu(e), 'misc')
     return _lin(e, p, prefix + 'time_embed.2')
 
 
 def resblock(p, pre, x, emb, down=False):
     # openaimodel.py:275-301 (no scale-shift norm, dropout p=0); down=True: AvgPool2d(2) on h and x (:276-282, use_conv=False)
-    h = st(F.silu(_gn(x, p, pre + 'in_layers.0', 1e-5)))
+    h = st(F.silu(_gn(x, p, pre + 'in_layers.0', 1e-5)), 'norm')
     if down:
-        h = st(F.avg_pool2d(h, 2, 2))
-        x = st(F.avg_pool2d(x, 2, 2))
+        h = st(F.avg_pool2d(h, 2, 2), 'misc')
+        x = st(F.avg_pool2d(x, 2, 2), 'misc')
     h = _conv(h, p, pre + 'in_layers.2')
-    e = like(_lin(st(F.silu(emb)), p, pre + 'emb_layers.1'), h)      # emb_out = self.emb_layers(emb).type(h.dtype)
+    e = like(_lin(st(F.silu(emb), 'misc'), p, pre + 'emb_layers.1'), h)      # emb_out = self.emb_layers(emb).type(h.dtype)
     h = st(h + e[:, :, None, None])                                   # engine: emb row added in the conv's fp32 epilogue
-    h = st(_conv(st(F.silu(_gn(h, p, pre + 'out_layers.0', 1e-5))), p, pre + 'out_layers.3'))
+    h = st(_conv(st(F.silu(_gn(h, p, pre + 'out_layers.0', 1e-5)), 'norm'), p, pre + 'out_layers.3'))
     if (pre + 'skip_connection.weight') in p:
         x = st(_conv(x, p, pre + 'skip_connection', padding=0))
-    return st(x + h)
+    return st(x + h, 'resid')
 
 
 def attention(p, pre, x, ctx, heads, fp32_sim=False):
@@ -150,10 +150,10 @@ def _attention_engine(p, pre, x, ctx, heads, d, ln):
     q, k, v = split(q), split(k), split(v)
     s = torch.matmul(q, k.transpose(-1, -2))
     pr = torch.exp2(s - s.amax(dim=-1, keepdim=True))
-    p16 = st(pr)
+    p16 = st(pr, 'attn')
     spare_row = (d % 32) != 0
     den = (p16 if spare_row else pr).sum(dim=-1, keepdim=True)
-    o = st(torch.matmul(p16, v) / den).permute(0, 2, 1, 3).reshape(b, n, c)
+    o = st(torch.matmul(p16, v) / den, 'attn').permute(0, 2, 1, 3).reshape(b, n, c)
     return _lin(o, p, pre + 'to_out.0')
 
 
@@ -161,24 +161,24 @@ def transformer_block(p, pre, x, ctx, heads, fp32_sim=False):
     # attention.py:234-240
     if P.MODE == 'engine':      # norm1 / norm2 / norm3 live inside the GEMMs they feed
         d = x.shape[-1] // heads
-        x = st(st(_attention_engine(p, pre + 'attn1.', x, None, heads, d, pre + 'norm1')) + x)
-        x = st(st(_attention_engine(p, pre + 'attn2.', x, ctx, heads, d, pre + 'norm2')) + x)
+        x = st(st(_attention_engine(p, pre + 'attn1.', x, None, heads, d, pre + 'norm1')) + x, 'resid')
+        x = st(st(_attention_engine(p, pre + 'attn2.', x, ctx, heads, d, pre + 'norm2')) + x, 'resid')
         a, g = _ln_lin(p, x, pre + 'norm3', pre + 'ff.net.0.proj').chunk(2, dim=-1)
-        return st(st(_lin(st(a * F.gelu(g)), p, pre + 'ff.net.2')) + x)
-    x = st(st(attention(p, pre + 'attn1.', _ln(x, p, pre + 'norm1'), None, heads, fp32_sim)) + x)
-    x = st(st(attention(p, pre + 'attn2.', _ln(x, p, pre + 'norm2'), ctx, heads, fp32_sim)) + x)
+        return st(st(_lin(st(a * F.gelu(g)), p, pre + 'ff.net.2')) + x, 'resid')
+    x = st(st(attention(p, pre + 'attn1.', _ln(x, p, pre + 'norm1'), None, heads, fp32_sim)) + x, 'resid')
+    x = st(st(attention(p, pre + 'attn2.', _ln(x, p, pre + 'norm2'), ctx, heads, fp32_sim)) + x, 'resid')
     h = _ln(x, p, pre + 'norm3')
     h = _lin(h, p, pre + 'ff.net.0.proj')
     a, g = h.chunk(2, dim=-1)
     h = st(a * F.gelu(g))                               # exact erf GELU, attention.py:43-44; engine: GEGLU epilogue
-    return st(st(_lin(h, p, pre + 'ff.net.2')) + x)
+    return st(st(_lin(h, p, pre + 'ff.net.2')) + x, 'resid')
 
 
 def spatial_transformer(p, pre, x, ctx, heads, fp32_sim=False):
     # attention.py:275-292 ; GroupNorm eps 1e-6 (attention.py:76-77)
     b, c, hh, ww = x.shape
     x_in = x
-    x = st(_gn(x, p, pre + 'norm', 1e-6))
+    x = st(_gn(x, p, pre + 'norm', 1e-6), 'norm')
     x = st(_conv(x, p, pre + 'proj_in', padding=0))
     x = x.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
     x = transformer_block(p, pre + 'transformer_blocks.0.', x, ctx, heads, fp32_sim)
@@ -186,7 +186,7 @@ def spatial_transformer(p, pre, x, ctx, heads, fp32_sim=False):
     if fp32_sim:
         x = x.contiguous()        # the ControlNet-side copy does (controlnet/ldm/modules/attention.py:331); numerically a no-op
     x = st(_conv(x, p, pre + 'proj_out', padding=0))
-    return st(x + x_in)
+    return st(x + x_in, 'resid')
 
 
 def run_block(p, pre, layers, h, emb, ctx, fp32_sim=False):
@@ -219,13 +219,13 @@ def adapter_forward(p, pre, x, cin=4):
             ic, oc, down = body[k]
             b = f'{pre}body.{k}.'
             if down:
-                x = st(F.avg_pool2d(x, kernel_size=2, stride=2))
+                x = st(F.avg_pool2d(x, kernel_size=2, stride=2), 'misc')
             if ic != oc:
                 x = st(F.conv2d(x, wt(p[b + 'in_conv.weight']), p[b + 'in_conv.bias']))
             h = F.conv2d(x, wt(p[b + 'block1.weight']), p[b + 'block1.bias'], padding=1)
             h = st(F.relu(h))
             h = st(F.conv2d(h, wt(p[b + 'block2.weight']), p[b + 'block2.bias']))
-            x = st(h + x)
+            x = st(h + x, 'resid')
         feats.append(x)
     return feats
 
@@ -257,16 +257,16 @@ def unet_forward(p, cfg, x, t, ctx, prefix='', use_adapter=False, pcond=None,
     """
     inp, mid, out = arch.unet_blocks(cfg)
     emb = time_embed(p, prefix, t, cfg['model_channels'])
-    ctx = st(ctx)
-    h = st(x.float())                                # h = x.type(self.dtype)
+    ctx = st(ctx, 'misc')
+    h = st(x.float(), 'misc')                        # h = x.type(self.dtype)
     fa, fks = None, []
-    prompt = h if pcond is None else st(pcond)
+    prompt = h if pcond is None else st(pcond, 'misc')
     if use_adapter == 'time':      # use_time_adapter=True: fa = self.adapter(prompt, emb)  (openaimodel.py:843-844)
         fa = time_adapter_forward(p, prefix + 'adapter.', prompt, emb, cfg['in_channels'])
     elif use_adapter:
         fa = adapter_forward(p, prefix + 'adapter.', prompt, cfg['in_channels'])
     if conds is not None:
-        fks = [adapter_forward(p, f'{prefix}adapters.{kdx}.', st(cond), cfg['in_channels']) for kdx, cond in enumerate(conds)]
+        fks = [adapter_forward(p, f'{prefix}adapters.{kdx}.', st(cond, 'misc'), cfg['in_channels']) for kdx, cond in enumerate(conds)]
     controls = _control_lists(control)
     hs = []
     k = 0
@@ -276,25 +276,25 @@ def unet_forward(p, cfg, x, t, ctx, prefix='', use_adapter=False, pcond=None,
             if fks:                                  # fk = sum_k fas_list[k][idx]; h = h + fk + fa[idx]  (openaimodel.py:1301-1305)
                 fk = fks[0][k]
                 for f in fks[1:]:
-                    fk = st(fk + f[k])
-                h = st(h + fk)
-            h = st(h + fa[k])
+                    fk = st(fk + f[k], 'resid')
+                h = st(h + fk, 'resid')
+            h = st(h + fa[k], 'resid')
             k += 1
         hs.append(h)
     if fa is not None:
         assert k == len(fa)
     h = run_block(p, f'{prefix}middle_block.', mid, h, emb, ctx, fp32_sim)
     for c in controls:
-        h = st(h + c.pop())                          # h += control.pop()  (cldm.py:40)
+        h = st(h + c.pop(), 'resid')                          # h += control.pop()  (cldm.py:40)
     for i, layers in enumerate(out):
         skip = hs.pop()
         if not only_mid_control:
             for c in controls:
-                skip = st(skip + c.pop())            # hs.pop() + control.pop()  (cldm.py:46)
+                skip = st(skip + c.pop(), 'resid')            # hs.pop() + control.pop()  (cldm.py:46)
         h = torch.cat([h, skip], dim=1)
         h = run_block(p, f'{prefix}output_blocks.{i}.', layers, h, emb, ctx, fp32_sim)
     h = like(h, x.float())                           # h = h.type(x.dtype)
-    h = st(F.silu(_gn(h, p, prefix + 'out.0', 1e-5)))
+    h = st(F.silu(_gn(h, p, prefix + 'out.0', 1e-5)), 'norm')
     return F.conv2d(h, wt(p[prefix + 'out.2.weight']), p[prefix + 'out.2.bias'], padding=1)
 
 
@@ -310,7 +310,7 @@ def _control_lists(control):
 
 def hint_block(p, prefix, hint):
     # cldm.py:655-671: 8 conv3x3, SiLU between, stride 2 at convs 2,4,6 (0-based)
-    h = st(hint.float())
+    h = st(hint.float(), 'misc')
     for k in range(8):
         stride = 2 if k in (2, 4, 6) else 1
         h = F.conv2d(h, wt(p[f'{prefix}input_hint_block.{2 * k}.weight']),
@@ -327,12 +327,12 @@ def controlnet_forward(p, cfg, x, hint, t, ctx, prefix=''):
     emb = time_embed(p, prefix, t, cfg['model_channels'])
     guided = hint_block(p, prefix, hint)
     outs = []
-    ctx = st(ctx)
-    h = st(x.float())
+    ctx = st(ctx, 'misc')
+    h = st(x.float(), 'misc')
     for i, layers in enumerate(inp):
         h = run_block(p, f'{prefix}input_blocks.{i}.', layers, h, emb, ctx, fp32_sim=True)
         if guided is not None:
-            h = st(h + guided)
+            h = st(h + guided, 'resid')
             guided = None
         # zero convs: raw (unscaled, and in 'engine' mode unrounded: the engine applies scale, rounding and the add into
         # the UNet's skip tensor in the same epilogue)

@@ -34,13 +34,39 @@ import torch
 
 MODE = 'fp32'
 _wcache = {}
+# Round 4: which CLASS of stored tensors carries the activation share of the engine policy's distance from the
+# fp32 path?  Every st() call in oracle.nn names its class; classes listed in EXACT stay exact fp32 in 'engine' mode
+# (precision.exact('resid') ...).  tools/parity_decompose.py prints the table; no product code reads this.
+#   'resid'  the residual stream: results of residual / skip / control / adapter-feature adds (what the next block starts from)
+#   'norm'   GroupNorm(+SiLU) / LayerNorm outputs
+#   'gemm'   convolution / Linear outputs (fused epilogues included: + emb row, GEGLU, ControlNet scale, q / k / v)
+#   'attn'   attention probabilities and the attention output before to_out
+#   'misc'   inputs (x, context, hint), pooled tensors, the timestep embedding chain
+CLASSES = ('resid', 'norm', 'gemm', 'attn', 'misc')
+EXACT = frozenset()
 
 
-def st(x):
-    """A tensor the engine stores to HBM between kernels: fp16 rounding in 'engine' mode, identity otherwise."""
-    if MODE == 'engine':
+def st(x, cls='gemm'):
+    """A tensor the engine stores to HBM between kernels: fp16 rounding in 'engine' mode (unless its class is in EXACT), identity
+    otherwise."""
+    if MODE == 'engine' and cls not in EXACT:
         return x.half().float()
     return x
+
+
+@contextlib.contextmanager
+def exact(*classes):
+    """Inside ``with precision.mode('engine'), precision.exact('resid'):`` tensors of the named classes are not rounded."""
+    global EXACT
+    for c in classes:
+        if c not in CLASSES:
+            raise ValueError(c)
+    prev = EXACT
+    EXACT = frozenset(classes)
+    try:
+        yield
+    finally:
+        EXACT = prev
 
 
 def wt(t, scale=None):

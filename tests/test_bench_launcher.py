@@ -29,6 +29,20 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert 'starting 2 ranks' in r.stderr
 
 
+def test_bench_gpus4_shards_the_configs3_batch():
+    """BASELINE configs[3]: 32 prompts over 4 GPUs = 8 per rank.  World size 4 over gloo (CPU rehearsal, analytic stand-in model):
+    four ranks come up, every rank gets its 8-prompt shard, rank 0 prints the one line."""
+    r = _run(['--gpus', '4', '--backend', 'gloo', '--dry-run', '--steps', '1', '--warmup', '0', '--prompts', '8', '--ddim-steps', '4',
+              '--controlnets', '2'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j['dry_run'] is True and j['n_gpus'] == 4 and len(j['per_rank_images_per_s']) == 4
+    assert j['config']['prompts_per_gpu'] == 8 and j['scaling'] == 'weak'
+    assert 'starting 4 ranks' in r.stderr
+
+
 def test_bench_refuses_cpu_product_run():
     """No silent CPU fallback: gloo without --dry-run is refused, and so is a dry run over nccl."""
     r = _run(['--gpus', '1', '--backend', 'gloo'])

@@ -1,0 +1,63 @@
+"""BASELINE configs[3] / [4] at full size: the SD-v1.5-width UNet with TWO (seg + depth) and THREE (seg + depth + normal) ControlNets,
+latent 64 x 64, hints 512 x 512, one classifier-free-guidance pair of rows per case, against the CPU oracle in its three precision
+modes (what's missing 3: until round 4 these networks met the oracle at 16 x 16 only, and the full size ran under an
+`isfinite` assert -- exactly where round 3's three-ControlNet workspace bug hid).  Several control models on one UNet are not in
+the reference (one control_model per ControlLDM, controlnet/cldm/cldm.py:820); they are defined as the sum of the scaled residual
+lists, the reference's own precedent for summed conditions being ldm/modules/diffusionmodules/openaimodel.py:1299-1306.
+The same rows are evaluated plain and with FGDM_FLAG_CFG_PAIRS (bit-identical), so the grouped N-way launches, the per-ControlNet
+workspace arenas and the shared CFG prefix are all on the measured path."""
+import pytest
+import torch
+
+import golden_inputs as gi
+from common import check_net_vs_oracle
+from fgdm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('ncn', [2, 3])
+def test_cfg_pair_at_full_size_with_several_controlnets_vs_oracle(ncn):
+    from fgdm_amd import _lib, models
+    from oracle import nn as onn
+    m = models.ControlLDM(gi.SD_CFG, n_controlnets=ncn)
+    try:
+        sd = {k: synth.make_tensor(k, s) for k, s in m.engine.param_shapes().items()}
+        assert not m.load_state_dict(sd)[0]
+        x = torch.from_numpy(synth.latents(1, 64, 64, seed=42))
+        c, uc = torch.from_numpy(synth.context(1, seed=43)), torch.from_numpy(synth.context(1, seed=44))
+        hints = [torch.from_numpy(synth.hint(1, 512, seed=45 + k)) for k in range(ncn)]
+        e = m.engine
+        for k, h in enumerate(hints):
+            e.set_hint(k, h.cuda())
+        xx, cc = torch.cat([x, x]), torch.cat([uc, c])
+        t = torch.tensor([981, 981])
+        plain = e.apply_model(xx.cuda(), t.cuda(), cc.cuda()).clone()
+        pairs = e.apply_model(xx.cuda(), t.cuda(), cc.cuda(), flags=_lib.FLAG_CFG_PAIRS)
+        assert torch.isfinite(plain).all() and torch.equal(plain, pairs)
+        # two prompts' pairs (4 rows): from here on the layers take the pipelined tiles, whose twin launches are FUSED; the engine's
+        # counters must say that grouped launches ran at this size, the shared-prefix path must not move a bit, and the rows must
+        # agree with the two-row evaluation above (other tiles there: rounding placement and summation order differ, nothing else)
+        from common import relerr
+        x4, c4, t4 = torch.cat([xx, xx]).cuda(), torch.cat([uc, uc, c, c]).cuda(), torch.tensor([981] * 4).cuda()
+        for k, h in enumerate(hints):
+            e.set_hint(k, torch.cat([h] * 4).cuda())
+        before = e.launch_stats()['fused_launches']
+        four_plain = e.apply_model(x4, t4, c4).clone()
+        assert e.launch_stats()['fused_launches'] > before, e.launch_stats()
+        for k, h in enumerate(hints):
+            e.set_hint(k, torch.cat([h, h]).cuda())
+        four = e.apply_model(x4, t4, c4, flags=_lib.FLAG_CFG_PAIRS)
+        assert torch.isfinite(four).all() and torch.equal(four, four_plain)
+        assert torch.equal(four[0], four[1]) and torch.equal(four[2], four[3])
+        assert relerr(four[0].cpu(), plain[0].cpu()) < 4e-3 and relerr(four[2].cpu(), plain[1].cpu()) < 4e-3
+        for k, h in enumerate(hints):
+            e.set_hint(k, h.cuda())
+        p = {k: torch.from_numpy(v) for k, v in sd.items()}
+        del sd
+        prefixes = ('control_model.',) + tuple(f'control_model_{k}.' for k in range(1, ncn))
+        hh = [torch.cat([h, h]) for h in hints]
+        check_net_vs_oracle(f'full-size SD UNet + {ncn} ControlNets (summed residuals), CFG pair, t=981', plain.cpu(),
+                            lambda: onn.control_ldm_apply(p, gi.SD_CFG, xx, t, cc, hh, cn_prefixes=prefixes))
+    finally:
+        m.engine.close()

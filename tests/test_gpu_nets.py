@@ -369,19 +369,25 @@ def test_broadcast_layout_is_bit_identical_to_fp32_load():
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
-@pytest.mark.parametrize('ncn', [2, 3])
-@pytest.mark.parametrize('knob', ['FGDM_PAIR_LAUNCH', 'FGDM_TWIN_STREAMS'])
-def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, ncn, monkeypatch):
-    """The UNet encoder and the ControlNets are independent until the UNet's middle block (cldm.py:40,46).  Default: both walks are
-    recorded and replayed in lockstep, twin GEMM launches fused into grouped launches (FGDM_PAIR_LAUNCH, on); opt-in: the ControlNets
-    on a second stream (FGDM_TWIN_STREAMS).  Neither may change a bit of eps: same kernels, same order per net.  Three ControlNets:
-    the second and third are replayed INTERLEAVED with each other (their recorded walks must not share workspace blocks)."""
+@pytest.mark.parametrize('knob,off,on,ncn', [('FGDM_PAIR_LAUNCH', '0', '1', 2), ('FGDM_PAIR_LAUNCH', '0', '1', 3), ('FGDM_PAIR_LAUNCH', '0', '1', 4),
+                                             ('FGDM_TWIN_STREAMS', '0', '1', 2), ('FGDM_GROUP_MAX', '2', '5', 3)])
+def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, off, on, ncn, monkeypatch):
+    """The UNet encoder and the ControlNets are independent until the UNet's middle block (cldm.py:40,46).  Default: all walks are
+    recorded and replayed in lockstep, twin GEMM launches of the UNet and ALL its ControlNets fused into grouped launches
+    (FGDM_PAIR_LAUNCH, on; FGDM_GROUP_MAX=2: pairwise, as in round 3); opt-in: the ControlNets on a second stream
+    (FGDM_TWIN_STREAMS).  None of them may change a bit of eps: same kernels, same order per net.  Every ControlNet records from a
+    workspace arena of its own (round 3: three ControlNets replayed interleaved from two arenas gave non-finite latents), so any
+    number up to the accepted four may replay side by side.  8 samples at 64 x 64 so that the layers take the pipelined tiles --
+    the only ones with a grouped kernel (at 2 x 32 x 32 nothing fused) -- and the engine's launch counters must say
+    that fused launches really ran, with more than two problems where the knob allows it."""
+    from fgdm_amd import _lib
     from fgdm_amd.engine import Engine
-    x, ctx = gi.get('small/x')[:2, :, :32, :32].contiguous(), gi.get('small/ctx')[:2]
-    hints = [gi.hint(2, 256, seed=5 + k) for k in range(ncn)]
-    t = torch.tensor([981, 21])
-    outs = []
-    for val in ('0', '1'):
+    B = 8
+    x, ctx = torch.from_numpy(synth.latents(B, 64, 64, seed=61)), torch.from_numpy(synth.context(B, seed=62))
+    hints = [torch.from_numpy(synth.hint(B, 512, seed=63 + k)) for k in range(ncn)]
+    t = torch.tensor([981, 21, 501, 1, 741, 301, 121, 881])
+    outs, stats = [], []
+    for val in (off, on):
         monkeypatch.setenv(knob, val)
         if knob == 'FGDM_TWIN_STREAMS':
             monkeypatch.setenv('FGDM_PAIR_LAUNCH', '0')
@@ -390,17 +396,24 @@ def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, ncn, mo
             for k, shp in e.param_shapes().items():
                 e.load_tensor(k, synth.make_tensor(small_rename(k), shp))
             e.finalize()
-            from fgdm_amd import _lib
             for c, h in enumerate(hints):
                 e.set_hint(c, h)
             outs.append(e.apply_model(x, t, ctx).cpu())
             # a classifier-free-guidance batch cat([x] * 2) with the shared-prefix path (hints of B / 2 rows)
             for c, h in enumerate(hints):
-                e.set_hint(c, h[:1].contiguous())
-            x2, t2 = torch.cat([x[:1], x[:1]]), torch.tensor([501, 501])
+                e.set_hint(c, h[:B // 2].contiguous())
+            x2, t2 = torch.cat([x[:B // 2], x[:B // 2]]), torch.cat([t[:B // 2], t[:B // 2]])
             outs.append(e.apply_model(x2, t2, ctx, flags=_lib.FLAG_CFG_PAIRS).cpu())
+            stats.append(e.launch_stats())
         finally:
             e.close()
     n = len(outs) // 2
+    assert all(torch.isfinite(o).all() for o in outs)
     for a, b in zip(outs[:n], outs[n:]):
         assert torch.equal(a, b), float((a - b).abs().max())
+    if knob == 'FGDM_PAIR_LAUNCH':
+        assert stats[0]['fused_launches'] == 0 and stats[1]['fused_launches'] > 50, stats
+        assert stats[1]['fused_problems'] > 2 * stats[1]['fused_launches'], stats          # the UNet + all ControlNets in one launch
+    if knob == 'FGDM_GROUP_MAX':
+        assert stats[0]['fused_launches'] > 0 and stats[0]['fused_problems'] == 2 * stats[0]['fused_launches'], stats
+        assert stats[1]['fused_problems'] >= (1 + ncn) * 50 and stats[1]['fused_launches'] < stats[0]['fused_launches'], stats

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV (too large to keep) into a small JSON: per-kernel-family time,
-device busy fraction and the distribution of idle gaps between consecutive kernels of the last sampling pass.
-Usage: python tools/trace_summary.py <..._kernel_trace.csv> <out.json> [fraction_of_trace_to_keep=0.45]"""
+device busy fraction and the distribution of idle gaps between consecutive kernels of the LAST SAMPLING PASS.
+The pass is cut by kernel names (round 4): from the first k_timestep_embed behind the
+(ddim_steps + 1)-th last k_ddim_step (or the start of the trace) to the last k_ddim_step -- the hint block and the context
+projections of that pass's first step included, the first-stage decodes behind it excluded.
+Usage: python tools/trace_summary.py <..._kernel_trace.csv> <out.json> [ddim_steps=50]"""
 import csv
 import json
 import sys
@@ -21,12 +24,20 @@ def family(name):
 
 def main():
     path, out = sys.argv[1:3]
-    keep = float(sys.argv[3]) if len(sys.argv) > 3 else 0.45
+    nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
-    rows = rows[int(len(rows) * (1.0 - keep)):]          # tail of the trace = inside the timed sampling pass
+    steps = [i for i, r in enumerate(rows) if 'k_ddim_step' in r[2]]
+    if len(steps) < nsteps:
+        raise SystemExit(f'trace holds {len(steps)} k_ddim_step launches, need {nsteps}')
+    last = steps[-1]
+    prev_end = steps[-nsteps - 1] if len(steps) > nsteps else -1       # last sampler update of the pass before this one
+    # the pass's own set-up work (hint block, context K / V projections) sits between prev_end and its first k_timestep_embed:
+    # count it, as bench.py's timed region does
+    first = prev_end + 1
+    rows = rows[first:last + 1]
     st = np.array([r[0] for r in rows], dtype=np.int64)
     en = np.array([r[1] for r in rows], dtype=np.int64)
     dur = en - st
@@ -42,6 +53,7 @@ def main():
     big_list = [{'gap_us': float(gaps[i]) / 1e3, 'after': rows[i][2][:60], 'before': rows[i + 1][2][:60],
                  'kernel_index': i} for i in big]
     res = {
+        'window': f'last sampling pass: kernels {first}..{last} of the trace ({nsteps} k_ddim_step launches; decode excluded)',
         'kernels': len(rows), 'span_ms': span / 1e6, 'kernel_sum_ms': float(dur.sum()) / 1e6,
         'busy_fraction': float(dur.sum()) / span,
         'gap_total_ms': float(gaps.sum()) / 1e6, 'gap_mean_us': float(gaps.mean()) / 1e3,
