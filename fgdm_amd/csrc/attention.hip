@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dq_kernel(const half_t* __res
 // V^T fragment is again one ds_read_b128.  The constant rows of V^T (ones row, zero rows) are part of the LDS image (written once
 // per slot; the DMA fills rows 0 .. D - 1 only), so only the K fragment of the fold slot needs a per-lane address.
 template <int D, int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, 2) void attn_dq32_kernel(const half_t* __restrict__ Q, int ldq,
+__global__ __launch_bounds__(NW * 64, D <= 40 ? 2 : 1) void attn_dq32_kernel(const half_t* __restrict__ Q, int ldq,
                                                            const half_t* __restrict__ K, int ldk,
                                                            const half_t* __restrict__ Vt, int ldvt,
                                                            half_t* __restrict__ O, int ldo,
@@ -1251,7 +1251,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dq32_kernel(const half_t* __r
     constexpr int NSLOT = 3;
     constexpr int NDMA = (KBYTES + VDATA) / 1024, NI = (NDMA + NW - 1) / NW;   // 1 KiB LDS-DMA wave-instructions per tile; per wave
     static_assert(KBYTES % 1024 == 0 && VDATA % 1024 == 0 && NDMA >= NW, "whole wave-instructions per image");
-    static_assert((KROW / 4) % 8 == 4, "K row stride: 4 mod 8 dwords so that sixteen consecutive rows tile the banks");
+    // K row stride: 4 mod 8 dwords makes sixteen consecutive rows tile the banks (d = 40: 80-byte rows).  d = 80 (160-byte rows: rows
+    // r and r + 8 would meet in the same banks): the 16-byte pieces of rows with (r >> 3) & 1 are ROTATED by ROT = 5 positions,
+    // half a row, on the source side -- sixteen consecutive rows then tile the banks again
+    constexpr int ROT = (KROW / 4) % 8 == 4 ? 0 : DC / 2;
+    static_assert(ROT == 0 || ((KROW / 4) % 16 == 8 && DC % 2 == 0), "K row stride");
     __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT + 64];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1299,7 +1303,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dq32_kernel(const half_t* __r
             const int L = 64 * j + lane, rp = L / DC, c = L - rp * DC;
             const int rho = rp & 31, a = rho >> 3;
             const int key = (rp & 32) + 16 * (a >> 1) + 8 * ((rho >> 2) & 1) + 4 * (a & 1) + (rho & 3);
-            voff[u] = (unsigned)(key * ldk + c * 8) * 2u;
+            const int cs = (c + DC - ROT * ((rho >> 3) & 1)) % DC;           // LDS position c of this row holds source piece cs
+            voff[u] = (unsigned)(key * ldk + cs * 8) * 2u;
         } else {
             const int L = 64 * (j - KBYTES / 1024) + lane, d = L >> 3, x = L & 7;
             voff[u] = (unsigned)(d * ldvt + ((x ^ ((d >> 1) & 7)) * 8)) * 2u;
@@ -1339,7 +1344,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dq32_kernel(const half_t* __r
 
     // ---- fragment addresses inside a slot.  K: row (32 sub + n32), piece 2 s + h -> immediate offsets 32 KROW sub + 32 s;
     // pieces >= DC are the constants.  V^T: row 32 t + n32, source piece 4 sub + 2 s2 + h at position (that) ^ ((n32 >> 1) & 7).
-    const int k_lane = n32 * KROW + h * 16;
+    int k_lane[NKS];                                         // byte offset of piece 2 s + h in this lane's row (rotated rows: see ROT)
+#pragma unroll
+    for (int s2 = 0; s2 < NKS; ++s2) k_lane[s2] = n32 * KROW + ((2 * s2 + h + ROT * ((n32 >> 3) & 1)) % DC) * 16;
     int v_lane[2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -1353,7 +1360,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dq32_kernel(const half_t* __r
 #define ATT_SB() __builtin_amdgcn_sched_barrier(0)
     auto rd_k = [&](const char* sl, int sub, int s) {
         const int ci0 = 2 * s;                               // piece index of lane half 0; half 1 reads ci0 + 1
-        const char* p = sl + k_lane + sub * 32 * KROW + s * 32;
+        const char* p = sl + k_lane[s] + sub * 32 * KROW;
         if (ci0 + 1 >= DC) {                                 // some lanes read a constant piece
             const char* cp0 = ci0 < DC ? p : (ci0 == DC ? c_one : c_zero);
             const char* cp1 = ci0 + 1 == DC ? c_one : c_zero;
@@ -1553,6 +1560,14 @@ int attention_launch(const half_t* Q, int ldq, const half_t* K, int ldk, const h
         }
         if (dq == 1) FGDM_LAUNCH((attn_dq_kernel<40, 4>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
         else FGDM_LAUNCH((attn_dq32_kernel<40, 4>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
+        return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+    }
+    // d = 80: the same kernel at one wave per SIMD (its two strands need ~280 registers); FGDM_ATTN_DQ80=0: the ping-pong kernel
+    static const int dq80 = getenv("FGDM_ATTN_DQ80") ? atoi(getenv("FGDM_ATTN_DQ80")) : 1;
+    if (dq80 > 0 && d == 80 && T % 256 == 0 && Tk % 64 == 0 && Tk >= 128 && (size_t)64 * ldk * 2 < (1u << 31) &&
+        (size_t)d * ldvt * 2 < (1u << 31)) {
+        const dim3 gridq((T / 256) * H * B), blockq(256);
+        FGDM_LAUNCH((attn_dq32_kernel<80, 4>), gridq, blockq, 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, H, T, Tk, sl2e);
         return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
     }
     if (pp_on && T >= 256 && Tk >= 256 && (d == 40 || d == 80)) {

@@ -301,6 +301,7 @@ struct fgdm_engine {
     // FGDM_PAIR_LAUNCH (default on): the UNet encoder + middle block and the ControlNets are RECORDED (common.h, "deferred
     // launches") and replayed in lockstep on the one stream, twin GEMM launches fused into grouped launches (replay_zip)
     bool pair_launch = true;
+    int group_max = FGDM_MAX_GROUP;      // FGDM_GROUP_MAX (read at fgdm_create): 2 = round 3's pairwise replay; the A/B knob
     long paired_launches = 0, replayed_launches = 0, paired_problems = 0;      // fused launches; all replayed launches; problems in fused launches
     struct Deferred { const GemmW* w; Tensor src; int idx; float scale; Arena* owner; };
     Prof prof;
@@ -1683,8 +1684,6 @@ struct fgdm_engine {
         struct RecGuard { ~RecGuard() { g_rec = nullptr; igemm_set_pair_hint(1); } } rec_guard;   // whatever path leaves: recording ends
         if (paired) {
             static const bool fat = !(getenv("FGDM_PAIR_FAT_TILES") && atoi(getenv("FGDM_PAIR_FAT_TILES")) == 0);       // A/B knob
-            // FGDM_GROUP_MAX: 2 = round 3's pairwise replay (UNet + first ControlNet, the others two by two): the A/B knob
-            static const int group_max = getenv("FGDM_GROUP_MAX") ? std::max(2, std::min(FGDM_MAX_GROUP, atoi(getenv("FGDM_GROUP_MAX")))) : FGDM_MAX_GROUP;
             if (fat) igemm_set_pair_hint(std::min<int>(group_max, 1 + (int)cns.size()));
             int rc = FGDM_OK;
             for (size_t c = 0; c < cns.size() && rc == FGDM_OK; ++c) {
@@ -1752,7 +1751,6 @@ struct fgdm_engine {
         if (paired) {
             g_rec = nullptr;
             igemm_set_pair_hint(1);
-            static const int group_max = getenv("FGDM_GROUP_MAX") ? std::max(2, std::min(FGDM_MAX_GROUP, atoi(getenv("FGDM_GROUP_MAX")))) : FGDM_MAX_GROUP;
             // the UNet and ALL its ControlNets in one lockstep replay (FGDM_GROUP_MAX=2: pairwise, as in round 3)
             std::vector<std::vector<RecOp>*> lists{&rec_un};
             for (size_t c = 0; c < rec_cn.size(); ++c) {
@@ -2029,6 +2027,7 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
     }
     if (const char* v = getenv("FGDM_TWIN_STREAMS")) e->twin_streams = atoi(v) != 0;
     if (const char* v = getenv("FGDM_PAIR_LAUNCH")) e->pair_launch = atoi(v) != 0;
+    if (const char* v = getenv("FGDM_GROUP_MAX")) e->group_max = std::max(2, std::min(FGDM_MAX_GROUP, atoi(v)));
     if (e->twin_streams && !e->cns.empty()) {
         if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -425,27 +425,29 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
         const int hwp = a.H * a.W, bimg = m0 / hwp, y0 = (m0 - bimg * hwp) / Wd;
         const int nsub = nk / 9;                                              // 32-channel sub-chunks
         // this wave's halo pieces: piece j = wave + u NW covers halo pixels [16 j, 16 j + 16), lane -> (pixel, k-piece)
-        unsigned h_b0[LH], h_b1[LH];
+        // (source pixel and byte offset of the k-piece, not one finished offset per source: selecting between two per-lane arrays by
+        // the run-time source made hipcc put them into scratch memory in the grouped instantiation)
+        unsigned h_pix[LH], h_pc[LH];
         bool h_ok[LH];
 #pragma unroll
         for (int u = 0; u < LH; ++u) {
             const int q = (wave + u * NW) * 64 + lane, hp = q >> 2, sp = q & 3;
             const int hr = hp / Pp, hx = hp - hr * Pp, y = y0 + hr - 1, x = hx - 1;
             h_ok[u] = hp < NPX && (unsigned)x < (unsigned)Wd && (unsigned)y < (unsigned)a.H;
-            const unsigned pix = (unsigned)(bimg * hwp + y * Wd + x), ch = (unsigned)((sp ^ ((hp >> 2) & 3)) << 3);
-            h_b0[u] = h_ok[u] ? (pix * (unsigned)a.C0 + ch) * 2u : 0u;
-            h_b1[u] = h_ok[u] ? (pix * (unsigned)a.C1 + ch) * 2u : 0u;
+            h_pix[u] = h_ok[u] ? (unsigned)(bimg * hwp + y * Wd + x) : 0u;
+            h_pc[u] = (unsigned)((sp ^ ((hp >> 2) & 3)) << 4);
         }
         const unsigned lds_h = __builtin_amdgcn_readfirstlane(lds_addr(smem)), lds_w = lds_h + 2 * HB;
         auto issue_halo = [&](int sub) {                                      // halo of sub-chunk `sub` -> buffer sub & 1
             const int cch = sub << 5;
             const bool s1 = cch >= a.C0;
             const char* sb = s1 ? (const char*)(a.A1 + (cch - a.C0)) : (const char*)(a.A0 + cch);
+            const unsigned rowb = (unsigned)(s1 ? a.C1 : a.C0) * 2u;      // bytes per pixel of that source
             const unsigned lb = lds_h + (unsigned)(sub & 1) * HB;
 #pragma unroll
             for (int u = 0; u < LH; ++u)
                 if (wave + u * NW < HPCS) {
-                    const char* ptr = h_ok[u] ? sb + (s1 ? h_b1[u] : h_b0[u]) : (const char*)a.zero;
+                    const char* ptr = h_ok[u] ? sb + (h_pix[u] * rowb + h_pc[u]) : (const char*)a.zero;
                     glds16_m0(ptr, lb + (unsigned)(wave + u * NW) * 1024u);
                 }
         };
