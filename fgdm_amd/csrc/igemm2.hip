@@ -415,15 +415,19 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
         //     sample's bits do not depend on the batch it is evaluated in;
         //   * the halo of the next 32 channels is requested in the first step of the current one and is eight steps old when its
         //     first fragments are read (behind that step's barrier); the buffer it overwrites was last read two steps before.
-        static_assert(CONV && MS == 16 && STAGES == 4 && !SPLIT && !ABL, "halo loop: 3x3 stride-1 convolution on the 16x16x32 MFMA");
+        static_assert(CONV && MS == 16 && STAGES == 4 && !ABL, "halo loop: 3x3 stride-1 convolution on the 16x16x32 MFMA");
         constexpr int RW = NI % 5 == 0 ? 5 : 4, WD = 3;
         static_assert(NI % RW == 0 && WD < RW && NI >= RW, "W ring");
         constexpr int HB = halo_px<BM>() * ROWB, HPCS = halo_px<BM>() / 16;   // bytes / 1 KiB pieces of a halo buffer
         constexpr int LH = (HPCS + NW - 1) / NW;                               // halo pieces per wave
         constexpr int WST = BN * ROWB;                                        // bytes of a weight stage
-        const int Wd = a.W, Pp = Wd + 2, NPX = (BM / Wd + 2) * Pp;
-        const int hwp = a.H * a.W, bimg = m0 / hwp, y0 = (m0 - bimg * hwp) / Wd;
-        const int nsub = nk / 9;                                              // 32-channel sub-chunks
+        // a halo buffer holds NSL slots of (RS + 2) x (W + 2) pixels: one slot = this tile's band of RS = BM / W rows of ONE image
+        // (H W >= BM), or NSL = BM / (H W) WHOLE images of RS = H rows each (the 8 x 8 level: four images per 256-row tile)
+        const int Wd = a.W, Pp = Wd + 2, hwp = a.H * a.W;
+        const bool whole = hwp < BM;
+        const int RS = whole ? a.H : BM / Wd, HP1 = (RS + 2) * Pp, NSL = whole ? BM / hwp : 1, NPX = NSL * HP1;
+        const int bimg = m0 / hwp, y0 = whole ? 0 : (m0 - bimg * hwp) / Wd;
+        const int nsub = nk / 9, sub0 = k_begin / 9;                          // 32-channel sub-chunks of this workgroup (split-K: its first one)
         // this wave's halo pieces: piece j = wave + u NW covers halo pixels [16 j, 16 j + 16), lane -> (pixel, k-piece)
         // (source pixel and byte offset of the k-piece, not one finished offset per source: selecting between two per-lane arrays by
         // the run-time source made hipcc put them into scratch memory in the grouped instantiation)
@@ -432,14 +436,14 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
 #pragma unroll
         for (int u = 0; u < LH; ++u) {
             const int q = (wave + u * NW) * 64 + lane, hp = q >> 2, sp = q & 3;
-            const int hr = hp / Pp, hx = hp - hr * Pp, y = y0 + hr - 1, x = hx - 1;
-            h_ok[u] = hp < NPX && (unsigned)x < (unsigned)Wd && (unsigned)y < (unsigned)a.H;
-            h_pix[u] = h_ok[u] ? (unsigned)(bimg * hwp + y * Wd + x) : 0u;
+            const int img = hp / HP1, rem = hp - img * HP1, hr = rem / Pp, hx = rem - hr * Pp, y = y0 + hr - 1, x = hx - 1;
+            h_ok[u] = hp < NPX && (unsigned)x < (unsigned)Wd && (unsigned)y < (unsigned)a.H && bimg + img < a.B;
+            h_pix[u] = h_ok[u] ? (unsigned)((bimg + img) * hwp + y * Wd + x) : 0u;
             h_pc[u] = (unsigned)((sp ^ ((hp >> 2) & 3)) << 4);
         }
         const unsigned lds_h = __builtin_amdgcn_readfirstlane(lds_addr(smem)), lds_w = lds_h + 2 * HB;
         auto issue_halo = [&](int sub) {                                      // halo of sub-chunk `sub` -> buffer sub & 1
-            const int cch = sub << 5;
+            const int cch = (sub0 + sub) << 5;
             const bool s1 = cch >= a.C0;
             const char* sb = s1 ? (const char*)(a.A1 + (cch - a.C0)) : (const char*)(a.A0 + cch);
             const unsigned rowb = (unsigned)(s1 ? a.C1 : a.C0) * 2u;      // bytes per pixel of that source
@@ -452,14 +456,14 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
                 }
         };
         // weight stage of step (sub, tap): the packed order is ((chunk64 * 9 + tap) * 2 + half) * 32
-        auto w_src = [&](int sub, int tp) { return (const char*)a.Wt + ((size_t)(((sub >> 1) * 9 + tp) * 64 + (sub & 1) * 32) << 1); };
+        auto w_src = [&](int sub, int tp) { const int sa = sub0 + sub; return (const char*)a.Wt + ((size_t)(((sa >> 1) * 9 + tp) * 64 + (sa & 1) * 32) << 1); };
         auto issue_w = [&](int kn, int sub, int tp, int p) { glds16_sv(b_b[p], w_src(sub, tp), lds_w + (unsigned)(kn & 3) * WST + (unsigned)(b_lds[p] - A_BYTES)); };
         // fragment reads.  X: this lane's pixel of fragment i sits at halo pixel hpc[i] (+ the tap's displacement)
         int hpc[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int pl = wm * TM + i * MS + lrow, r = pl / Wd, x = pl - r * Wd;
-            hpc[i] = (r + 1) * Pp + x + 1;
+            const int pl = wm * TM + i * MS + lrow, img = pl / (RS * Wd), rem = pl - img * RS * Wd, r = rem / Wd, x = rem - r * Wd;
+            hpc[i] = img * HP1 + (r + 1) * Pp + x + 1;
         }
         auto rdXh = [&](int sub, int tp, int i) {
             const int hp = hpc[i] + (tp / 3 - 1) * Pp + (tp - (tp / 3) * 3 - 1);
@@ -1032,6 +1036,14 @@ int igemm_splitk_reduce(const IgemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
+// The halo loop (PIPE = 2) serves stride-1 3x3 convolutions whose row tiles -- of BOTH tile heights, 256 and 128 rows -- are whole rows
+// of one image (W = 16 / 32 / 64, H W a multiple of 256) or whole 8 x 8 images: a property of the layer's geometry, never of the batch
+static bool halo_geometry(const IgemmArgs& a) {
+    if (a.mode != IG_CONV3 || a.Ho != a.H || a.Wo != a.W || (a.C0 & 63) || (a.C1 & 63) || (a.K % 288) || a.debug) return false;
+    if ((a.W == 16 || a.W == 32 || a.W == 64) && (a.H * a.W) % 256 == 0) return true;
+    return a.W == 8 && a.H == 8;
+}
+
 // cfg & 15: 0 = 256x320   1 = 256x256 (GEGLU-capable)   2 = 128x320   6 = 256x128   (8 waves, 4-stage ring, 16x16x32 MFMA)
 //           7 = 64x160, four waves, two workgroups per CU: the linears of the 8x8 level (M = 64 rows per sample), whose grids
 //               cannot fill the chip with taller tiles
@@ -1050,6 +1062,12 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if (a.act == ACT_GEGLU && bn != 256) return FGDM_ERR_ARG;
     if (a.splitk > 1) {
         if ((tile != 2 && tile != 0) || a.ln_stats) return FGDM_ERR_ARG;
+        // the halo loop for split K too (round 4): every K slice must be whole 32-channel sub-chunks (nine steps each)
+        static const bool halo_sk = !(getenv("FGDM_IGEMM_HALO") && atoi(getenv("FGDM_IGEMM_HALO")) == 0);
+        const int nk_all = a.K >> 5;
+        if (halo_sk && pipe && halo_geometry(a) && nk_all % a.splitk == 0 && (nk_all / a.splitk) % 9 == 0)
+            return tile == 0 ? launch2<256, 320, 4, 2, 4, true, false, true, 16, false, false, 2>(a, s)
+                             : launch2<128, 320, 4, 2, 4, true, false, true, 16, false, false, 2>(a, s);
         if (tile == 0 && pipe)       // (the phase-locked loop has no 256 x 320 split-K instantiation: 128 x 320 below)
             return a.mode == IG_LINEAR ? launch2<256, 320, 4, 2, 4, false, false, true, 16, false, false, 1>(a, s)
                                        : launch2<256, 320, 4, 2, 4, true, false, true, 16, false, false, 1>(a, s);
@@ -1060,11 +1078,9 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
                                    : launch2<128, 320, 4, 2, 4, true, false, true, 16, false, false, 0>(a, s);
     }
     if (a.ln_stats && a.mode != IG_LINEAR) return FGDM_ERR_ARG;
-    // the halo loop (PIPE = 2): stride-1 3x3 convolutions whose row tiles are whole image rows of ONE image for both tile heights
-    // (W = 16 / 32 / 64, H W a multiple of 256): a property of the layer's geometry, never of the batch.  FGDM_IGEMM_HALO=0: A/B knob
+    // the halo loop (PIPE = 2) where the geometry allows it (halo_geometry).  FGDM_IGEMM_HALO=0: A/B knob
     static const bool halo_on = !(getenv("FGDM_IGEMM_HALO") && atoi(getenv("FGDM_IGEMM_HALO")) == 0);
-    const bool halo = halo_on && pipe && a.mode == IG_CONV3 && a.Ho == a.H && a.Wo == a.W && (a.W == 16 || a.W == 32 || a.W == 64) &&
-                      (a.H * a.W) % 256 == 0 && !(a.C0 & 63) && !(a.C1 & 63) && !(a.K % 288) && !a.debug;
+    const bool halo = halo_on && pipe && halo_geometry(a);
     switch (tile) {
         case 0: return halo ? launch_tile<256, 320, 16, 2>(a, s) : pipe ? launch_tile<256, 320, 16, 1>(a, s) : launch_tile<256, 320, 16, 0>(a, s);
         case 1: return pipe ? launch_tile<256, 256, 16, 1>(a, s) : launch_tile<256, 256, 16, 0>(a, s);

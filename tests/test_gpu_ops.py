@@ -283,7 +283,7 @@ BIG_CASES += [
 # the halo loop (igemm2.hip PIPE = 2, round 4): stride-1 3x3 convolutions whose row tiles are whole rows of one image -- W = 16 /
 # 32 / 64 and H W a multiple of 256 -- on both tile heights (cfg 4: 256 x 320, cfg 6: 128 x 320): image borders on every side of
 # a tile, tiles in the middle of an image (top / bottom halo rows from the neighbouring tiles' rows), the virtual concat with
-# the source switch inside the K walk, every epilogue kind, several samples; W = 8 and H W = 128 stay on the per-tap loop
+# the source switch inside the K walk, every epilogue kind, several samples; whole 8 x 8 images (with an M tail); 16 x 8 and H W = 128 stay on the per-tap loop
 BIG_CASES += [
     (4, 1, 16, 16, 128, 0, 320, 3, 1, 0, 0, 'cfg4 halo 16x16 one tile = one image'),
     (4, 3, 16, 16, 64, 64, 640, 3, 1, 0, 1, 'cfg4 halo 16x16 concat silu + rowvec + resid'),
@@ -294,7 +294,9 @@ BIG_CASES += [
     (6, 2, 16, 16, 192, 0, 320, 3, 1, 0, 1, 'cfg6 halo 16x16 (2 tiles per image) silu + rowvec + resid'),
     (6, 1, 32, 32, 64, 64, 640, 3, 1, 0, 0, 'cfg6 halo 32x32 concat'),
     (6, 1, 64, 64, 128, 0, 320, 3, 1, 0, 0, 'cfg6 halo 64x64 (2-row tiles) rowvec + resid'),
-    (4, 2, 16, 8, 128, 0, 320, 3, 1, 0, 0, 'cfg4 W=8: per-tap loop'),
+    (4, 5, 8, 8, 128, 64, 320, 3, 1, 0, 1, 'cfg4 halo 8x8 whole images (4 per tile), M tail, concat silu + rowvec + resid'),
+    (6, 3, 8, 8, 192, 0, 640, 3, 1, 0, 0, 'cfg6 halo 8x8 whole images (2 per tile), M tail'),
+    (4, 2, 16, 8, 128, 0, 320, 3, 1, 0, 0, 'cfg4 16x8: per-tap loop'),
     (6, 1, 2, 64, 128, 0, 320, 3, 1, 0, 0, 'cfg6 H W = 128: per-tap loop'),
 ]
 
