@@ -46,7 +46,11 @@ def report(name, err, tol):
 # only in fp32 summation order decorrelate to the same level (test_fp16_storage_is_chaotic).  So a network-level check is
 #     err(engine, reference fp32)  <=  max(1e-3, NET_K * floor)      with the floor MEASURED on the same inputs,
 # i.e. the engine is no farther from the CPU path than the reference's own GPU numerics are.
-NET_K = 1.1
+# Round 4: the factor is the measured worst err / floor over the 54 network comparisons of the GPU suite
+# (profiles/r04_parity_errors.txt: 1.038, `AdaptUNetModel conds`; 0.91 ... 1.04 overall) plus 5 %.  tools/parity_decompose.py shows
+# why it cannot be pushed towards the literal 1e-3: fp16 weights alone cost 0.98e-3 and no single class of stored activations,
+# kept exact, brings a whole evaluation below 1.48e-3.
+NET_K = 1.09
 # ... capped absolutely (the floor comes from this repo's CPU emulation of CUDA autocast, oracle/autocast.py: an error there must
 # not be able to widen the gate): one network evaluation 4e-3; several chained evaluations, or an evaluation whose CFG combine
 # (scale 9) multiplies the difference of two evaluations, 1e-2 -- the callers that need the second say so (cap=CAP_CHAIN).
