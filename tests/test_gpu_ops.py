@@ -205,7 +205,10 @@ ATT_CASES = [(2, 8, 64, 64, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80),
              # the text-token kernel (64 < Tk <= 96, T >= 128): every head width, ragged T (a wave's last chunk partly / wholly
              # past the end), one and several chunks per wave, the key-count limits
              (2, 8, 1024, 77, 80), (2, 8, 512, 77, 160), (1, 8, 700, 77, 40), (3, 8, 130, 77, 80), (1, 8, 512, 96, 40),
-             (1, 8, 640, 65, 80), (2, 4, 256, 77, 160)]
+             (1, 8, 640, 65, 80), (2, 4, 256, 77, 160),
+             # long self-attention whose T is not a multiple of 256 (or Tk of 64): the eight-wave ping-pong kernel, which the
+             # two-strand kernels (round 4) replace only where their shape conditions hold
+             (1, 8, 320, 320, 40), (1, 8, 384, 300, 80), (2, 8, 512, 256, 40)]
 
 
 @pytest.mark.parametrize('case', ATT_CASES, ids=[f'B{c[0]}_H{c[1]}_T{c[2]}_Tk{c[3]}_d{c[4]}' for c in ATT_CASES])
@@ -354,6 +357,24 @@ def test_linear_pipelined_kernel(lib):
                 assert relerr(outT[:, :, :rps].float().cpu(), want) < TOL, (cfg, rps)
     finally:
         lib.fgdm_debug_force_igemm_cfg(0)
+
+
+@pytest.mark.parametrize('knob', ['FGDM_ATTN_DQ=1', 'FGDM_ATTN_DQ=0 FGDM_ATTN_DQ80=0'])
+def test_attention_alternative_kernels(knob):
+    """The kernels the default path no longer takes for the self-attention shapes -- the 16-wide form of the two-strand kernel
+    (FGDM_ATTN_DQ=1: faster on random operands, slower inside the network) and the ping-pong kernel for every long shape
+    (FGDM_ATTN_DQ=0 FGDM_ATTN_DQ80=0) -- stay selectable for same-box A/B runs, so they stay under the same parity cases.  The knobs
+    are read once per process: a fresh interpreter runs the attention cases under each."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for kv in knob.split():
+        k, v = kv.split('=')
+        env[k] = v
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                        'test_attention and not alternative'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
 
 
 @pytest.mark.parametrize('gain,shift', [(6.0, 0.0), (3.0, 2.0), (0.05, 0.0)], ids=['large logits', 'all-negative rows', 'flat rows'])
