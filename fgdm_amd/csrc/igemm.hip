@@ -339,10 +339,16 @@ static int pick_force(const IgemmArgs& a) {
         if (!geglu && a.N % 320 == 0) {
             const long b256 = (long)((a.M + 255) / 256) * (a.N / 320);
             const long b128 = (long)((a.M + 127) / 128) * (a.N / 320);
+            // 64x160 four-wave tiles (two workgroups per CU) for the linears whose 128-row grid cannot fill the chip: the 8x8
+            // level's (M = 64 rows per sample), and (round 4: FGDM_IGEMM_SMALL_M=0 switches it off) those whose 128 x 320 grid --
+            // times the number of problems a grouped launch will carry -- stays under three quarters of the CUs while the 64 x 160
+            // grid fills every CU twice: the 16x16 level at 8 prompts per GPU (M = 4096: 128 tiles of 128 x 320, 512 of 64 x 160)
+            static const bool small_m = !(getenv("FGDM_IGEMM_SMALL_M") && atoi(getenv("FGDM_IGEMM_SMALL_M")) == 0);              // A/B knob
+            const bool lin64 = a.mode == IG_LINEAR && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && small_tiles;
+            const long b64 = (long)((a.M + 63) / 64) * (a.N / 160);
             if (b256 * g_pair_mult >= 192) force = 4;
-            else if (b128 >= 96) force = 6;
-            else if (a.mode == IG_LINEAR && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && small_tiles &&
-                     (long)((a.M + 63) / 64) * (a.N / 160) >= 128) force = 11;     // 64x160 tiles: the 8x8 level's linears
+            else if (b128 >= 96 && !(small_m && lin64 && b128 * g_pair_mult < 192 && b64 >= 512)) force = 6;
+            else if (lin64 && b64 >= 128) force = 11;
         } else if (geglu && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= 128) {
             force = 5;
         } else if (!geglu && !a.ln_stats && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && other_widths) {
