@@ -46,6 +46,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--cfgs', default='0,4,5,6,7,8,9', help='force_cfg + 256 * ablation bits (IgemmArgs::debug), comma separated')
     ap.add_argument('--shapes', default='', help='only shapes whose name contains one of these comma-separated substrings')
+    ap.add_argument('--batch', type=int, default=0, help='override the batch (rows of the CFG batch) of every shape: how does the time scale with tiles per CU?')
     a = ap.parse_args()
     want = [w for w in a.shapes.split(',') if w]
     lib = _lib.load()
@@ -54,6 +55,8 @@ def main():
     for name, B, H, W, C0, C1, Co, ks, st, up, act, res in SHAPES:
         if want and not any(w in name for w in want):
             continue
+        if a.batch:
+            B = a.batch
         Ho, Wo = (2 * H, 2 * W) if up else (((H - 1) // 2 + 1, (W - 1) // 2 + 1) if st == 2 else (H, W))
         flops = 2.0 * B * Ho * Wo * Co * ks * ks * (C0 + C1)
         row = name.ljust(26)
