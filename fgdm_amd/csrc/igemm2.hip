@@ -873,6 +873,273 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_pair_kernel(const IgemmAr
     igemm2_body<BM, BN, WM, WN, STAGES, CONV, GEGLU, SPLIT, MS, LN, PATH, PIPE, ABL>(p.g[blockIdx.y]);
 }
 
+// =====================================================================================================================
+// Persistent GEGLU projection (round 4).  ff.net.0.proj (ldm/modules/attention.py:37-64) has K = C = 320 / 640 /
+// 1280: ten to forty K-steps per 256 x 256 tile and then an epilogue as long as the loop itself.  With one workgroup per CU the
+// tiles of a CU run strictly one after the other (tools/bench_igemm.py --batch: the time is linear in tiles per CU), so every tile
+// pays the latency of its first LDS-DMA stages in full.  Here 256 workgroups walk the tiles: behind a tile's K loop the first two
+// stages of the NEXT tile are requested (ring slots 0 and 1; the epilogue stages through slots 2 and 3), so they travel while the
+// current tile's bias / LayerNorm fix-up / GELU / pack / store runs; the third stage follows behind the epilogue.  The K loop and
+// the epilogue are the ones of igemm2_kernel<256, 256, 4, 2, 4, false, true, false, 16, LN, 1, 1, false> statement for statement
+// (same K order, same MFMA, same ln_scale / gelu2_f / roundings): the output does not change by a bit.
+// Only what that layer needs: LINEAR, one source, fp16 row-major output, no emb row, no residual, no second destination.
+template <bool LN>
+__global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmArgs a, int ntiles) {
+    constexpr int BM = 256, BN = 256, WM = 4, WN = 2, NW = 8, T = 512, STAGES = 4, MS = 16;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / MS, NI = TN / MS, AR = 4;
+    typedef float acc_t __attribute__((ext_vector_type(AR)));
+    constexpr int LA = BM * 4 / 64 / NW, LB = BN * 4 / 64 / NW, LPS = LA + LB;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB, A_BYTES = BM * ROWB, RING_BYTES = STAGES * STAGE_BYTES;
+    constexpr int OPS_FLOATS = BN + 2 * BM + BN;          // bias, (mean, rstd) per row, u  -- two sets (this tile's / the next one's)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto swz_of = [](int r) { return ((r >> 3) & 1) << 1; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = a.N / BN;
+    const int nk = a.K >> 5;
+    // tiles of this workgroup: XCD x = blockIdx & 7 owns a contiguous range of logical tiles (as in igemm2_kernel), its gridDim / 8
+    // workgroups take them round-robin
+    const int xcd = blockIdx.x & 7, G8 = gridDim.x >> 3, tq = ntiles >> 3, tr = ntiles & 7;
+    const int t_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, t_count = tq + (xcd < tr ? 1 : 0);
+    int local = blockIdx.x >> 3;
+    if (local >= t_count) return;
+
+    const int lrow = lane & (MS - 1), lh = lane / MS, lq = 4 * lh;
+    const int koff = lrow * ROWB + ((lh ^ swz_of(lrow)) << 4);
+    unsigned a_b0[LA], a_ok[LA], b_b[LB];
+    int b_lds[LB];
+    auto setup = [&](int m0x, int n0x) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int q = (wave + i * NW) * 64 + lane, r = q >> 2, sp = q & 3, m = m0x + r;
+            a_ok[i] = m < a.M ? 1u : 0u;
+            a_b0[i] = a_ok[i] ? ((unsigned)m * (unsigned)a.C0 + (unsigned)((sp ^ swz_of(r)) << 3)) * 2u : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int idx = wave + i * NW, q = idx * 64 + lane, r = q >> 2, sp = q & 3;
+            b_b[i] = ((unsigned)(n0x + r) * (unsigned)a.K + (unsigned)((sp ^ swz_of(r)) << 3)) * 2u;
+            b_lds[i] = A_BYTES + idx * 1024;
+        }
+    };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue_stage = [&](int kn) {                         // K-step kn of the tile set up last -> ring slot kn & 3
+        const char* sbase = (const char*)a.A0 + ((size_t)kn << 6);
+        const char* wbase = (const char*)a.Wt + ((size_t)kn << 6);
+        const unsigned lbase = lds0 + (unsigned)(kn & 3) * STAGE_BYTES;
+#pragma unroll
+        for (int p2 = 0; p2 < LA; ++p2) glds16_m0(a_ok[p2] ? sbase + a_b0[p2] : (const char*)a.zero, lbase + (unsigned)(wave + p2 * NW) * 1024u);
+#pragma unroll
+        for (int p2 = 0; p2 < LB; ++p2) glds16_sv(b_b[p2], wbase, lbase + (unsigned)b_lds[p2]);
+    };
+    float* const ops = (float*)(smem + RING_BYTES);
+    auto stage_ops = [&](int m0x, int n0x, int set) {        // epilogue operands of a tile -> LDS set `set`
+        float* bias_l = ops + set * OPS_FLOATS, *mr_l = bias_l + BN, *u_l = mr_l + 2 * BM;
+        for (int c = tid; c < BN; c += T) bias_l[c] = a.bias ? a.bias[n0x + c] : 0.f;
+        if constexpr (LN) {
+            for (int c = tid; c < BN; c += T) u_l[c] = a.ln_u[n0x + c];
+            for (int r = tid; r < BM; r += T) {      // partial sums in fixed slot order; E[x^2] - mean^2 in double (as igemm2_kernel)
+                float mean = 0.f, rstd = 0.f;
+                if (m0x + r < a.M) {
+                    const float* sp = a.ln_stats + (size_t)(m0x + r) * a.ln_slots * 2;
+                    float sm = 0.f, sq = 0.f;
+                    for (int p2 = 0; p2 < a.ln_slots; ++p2) { sm += sp[2 * p2]; sq += sp[2 * p2 + 1]; }
+                    const double mu = (double)sm / (double)a.C0;
+                    double var = (double)sq / (double)a.C0 - mu * mu;
+                    if (var < 0.0) var = 0.0;
+                    mean = (float)mu;
+                    rstd = (float)(1.0 / sqrt(var + (double)a.ln_eps));
+                }
+                mr_l[2 * r] = mean; mr_l[2 * r + 1] = rstd;
+            }
+        }
+    };
+
+    int logical = t_first + local;
+    int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
+    setup(m0, n0);
+#pragma unroll
+    for (int sg = 0; sg < STAGES - 1; ++sg)
+        if (sg < nk) issue_stage(sg);
+    stage_ops(m0, n0, 0);
+    int set = 0;
+    bool first = true;
+    for (;;) {
+        acc_t acc[NI][MI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < AR; ++r) acc[j][i][r] = 0.f;
+        // ---- K loop: igemm2_kernel's software-pipelined loop (PIPE = 1), LINEAR
+        constexpr int RW = 4, WD = 3;
+        auto rdX = [&](int kt, int i) { return *(const h8*)(smem + (kt & 3) * STAGE_BYTES + (wm * TM + i * MS) * ROWB + koff); };
+        auto rdW = [&](int kt, int j) { return *(const h8*)(smem + (kt & 3) * STAGE_BYTES + A_BYTES + (wn * TN + j * MS) * ROWB + koff); };
+        h8 xa[MI], xb[MI], wr[RW];
+        {
+            // stage 0 landed.  First tile: stages 1, 2 may fly.  Later tiles: stages 0, 1 were requested before the previous
+            // epilogue (whose stores are older than stage 2 as well): everything but stage 2 is waited for
+            if (first) {
+                const int younger = min(nk - 1, STAGES - 2);
+                if (younger >= 2) wait_vmcnt<2 * LPS>(); else if (younger == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            } else {
+                if (nk > 2) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xa[i] = rdX(0, i);
+#pragma unroll
+            for (int d = 0; d < WD; ++d) wr[d] = rdW(0, d);
+        }
+        auto step = [&](auto RF, int kt, h8 (&cur)[MI], h8 (&nxt)[MI]) {
+            constexpr bool REFILL = decltype(RF)::value;
+            if (REFILL || kt + 2 < nk) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            const char* sbase = (const char*)a.A0 + ((size_t)(kt + STAGES - 1) << 6);
+            const char* wbase = (const char*)a.Wt + ((size_t)(kt + STAGES - 1) << 6);
+            const unsigned lbase = lds0 + (unsigned)((kt + STAGES - 1) & 3) * STAGE_BYTES;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (REFILL) {
+#pragma unroll
+                    for (int p2 = 0; p2 < LPS; ++p2)
+                        if (p2 * NI / LPS == j) {
+                            if (p2 < LA) glds16_m0(a_ok[p2] ? sbase + a_b0[p2] : (const char*)a.zero, lbase + (unsigned)(wave + p2 * NW) * 1024u);
+                            else glds16_sv(b_b[p2 - LA], wbase, lbase + (unsigned)b_lds[p2 - LA]);
+                        }
+                }
+                { const int jn = j + WD; wr[jn % RW] = jn < NI ? rdW(kt, jn) : rdW(kt + 1, jn - NI); }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    if (i * NI / MI == j) nxt[i] = rdX(kt + 1, i);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j % RW], cur[i], acc[j][i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        {
+            const int nr = max(nk - (STAGES - 1), 0);
+            int kt = 0;
+            for (; kt + 1 < nr; kt += 2) {
+                step(std::true_type{}, kt, xa, xb);
+                step(std::true_type{}, kt + 1, xb, xa);
+            }
+            if (kt < nr) {
+                step(std::true_type{}, kt, xa, xb);
+                ++kt;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xa[i] = xb[i];
+            }
+            if (kt < nk) step(std::false_type{}, kt, xa, xb);
+            if (kt + 1 < nk) step(std::false_type{}, kt + 1, xb, xa);
+            if (kt + 2 < nk) step(std::false_type{}, kt + 2, xa, xb);
+            wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // all waves are out of the K loop: the ring is free
+        // ---- the next tile's first two stages start their trip now (ring slots 0, 1; the epilogue stages through slots 2, 3)
+        local += G8;
+        const bool more = local < t_count;
+        const int m0c = m0, n0c = n0;
+        if (more) {
+            logical = t_first + local;
+            m0 = (logical / ntn) * BM; n0 = (logical % ntn) * BN;
+            setup(m0, n0);
+            if (nk > 0) issue_stage(0);
+            if (nk > 1) issue_stage(1);
+        }
+        // ---- epilogue of the tile just finished: igemm2_kernel's GEGLU PATH 1, statement for statement
+        const float* bias_l = ops + set * OPS_FLOATS, *mr_l = bias_l + BN, *u_l = mr_l + 2 * BM;
+        if constexpr (LN) {
+            const float* uw = u_l + wn * TN;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 uq = *(const f32x4*)(uw + j * MS + lq);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int trow = wm * TM + i * MS + lrow;
+                    const float mean = mr_l[2 * trow], rstd = mr_l[2 * trow + 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][i][e] = ln_scale(acc[j][i][e], mean, rstd, uq[e]);
+                }
+            }
+        }
+        constexpr int OUT_TN = TN / 2, PITCH = OUT_TN * 2 + 8, CPR = OUT_TN / 8, WB_IT = (32 * CPR + 63) / 64, CST_BYTES = 32 * PITCH;
+        static_assert(NW * CST_BYTES <= 2 * STAGE_BYTES, "epilogue staging must fit ring slots 2 and 3");
+        char* cst = smem + 2 * STAGE_BYTES + wave * CST_BYTES;
+        const int ocol0 = (n0c + wn * TN) >> 1, nvalid = a.N / 2;
+        const float* bw = bias_l + wn * TN;
+#pragma unroll
+        for (int ip = 0; ip < TM / 32; ++ip) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int i = ip * 2 + hf;
+                const int prow = hf * MS + lrow;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (j & 2) continue;                      // gate tiles are consumed with their value tile
+                    const int wc = j * MS + lq;
+                    const f32x4 bq = *(const f32x4*)(bw + wc);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bq[e];
+                    const f32x4 gq = *(const f32x4*)(bw + wc + 32);
+                    const f32x2 g01 = gelu2_f(f32x2{acc[j + 2][i][0] + gq[0], acc[j + 2][i][1] + gq[1]});
+                    const f32x2 g23 = gelu2_f(f32x2{acc[j + 2][i][2] + gq[2], acc[j + 2][i][3] + gq[3]});
+                    v[0] *= g01[0]; v[1] *= g01[1]; v[2] *= g23[0]; v[3] *= g23[1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= a.scale;
+                    const int oc = (j >> 2) * 32 + (j & 1) * 16 + lq;
+                    const h4 pk = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *(h4*)(cst + prow * PITCH + oc * 2) = pk;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private tile: no barrier needed
+#pragma unroll
+            for (int it = 0; it < WB_IT; ++it) {
+                const int c = lane + it * 64, pr = c / CPR, ck = c - pr * CPR;
+                const int grow = m0c + wm * TM + ip * 32 + pr, gcol = ocol0 + ck * 8;
+                if (c < 32 * CPR && grow < a.M && gcol < nvalid) {
+                    const char* sp = cst + pr * PITCH + ck * 16;
+                    const h4 lo = *(const h4*)sp, hi = *(const h4*)(sp + 8);
+                    *(h8*)((half_t*)a.out + (size_t)grow * a.ld_out + gcol) = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
+        }
+        if (!more) break;
+        // ---- the next tile's epilogue operands (other LDS set), then -- behind a barrier: every wave is out of the staging
+        // slots -- its third stage
+        set ^= 1;
+        stage_ops(m0, n0, set);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nk > 2) issue_stage(2);
+        first = false;
+    }
+}
+
+template <bool LN>
+int launch_geglu_persist(const IgemmArgs& a, int ntiles, hipStream_t s) {
+    constexpr int smem = 4 * (256 + 256) * ROWB + 2 * (256 + 2 * 256 + 256) * 4;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    auto k = igemm2_geglu_persist_kernel<LN>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    FGDM_LAUNCH(k, dim3(256), dim3(512), smem, s, a, ntiles);
+    return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool GEGLU, bool SPLIT, int MS, bool LN, int PATH, int PIPE, bool ABL>
 int launch2p(const IgemmArgs& a, hipStream_t s) {
     constexpr int ring = ring_bytes<BM, BN, STAGES, PIPE>();
@@ -1078,6 +1345,14 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
                                    : launch2<128, 320, 4, 2, 4, true, false, true, 16, false, false, 0>(a, s);
     }
     if (a.ln_stats && a.mode != IG_LINEAR) return FGDM_ERR_ARG;
+    // the persistent GEGLU projection (igemm2_geglu_persist_kernel): 256 workgroups walk the tiles once there are more tiles than
+    // CUs.  FGDM_IGEMM_PERSIST=0: A/B knob (the outputs are bit-identical either way)
+    static const bool persist_on = !(getenv("FGDM_IGEMM_PERSIST") && atoi(getenv("FGDM_IGEMM_PERSIST")) == 0);
+    if (persist_on && tile == 1 && pipe && a.act == ACT_GEGLU && a.mode == IG_LINEAR && !a.C1 && a.out_kind == OUT_F16 && !a.rowvec &&
+        !a.resid && !a.out2 && !a.stats_out && !a.debug && a.N % 256 == 0) {
+        const int ntiles = ((a.M + 255) / 256) * (a.N / 256);
+        if (ntiles > 256) return a.ln_stats ? launch_geglu_persist<true>(a, ntiles, s) : launch_geglu_persist<false>(a, ntiles, s);
+    }
     // the halo loop (PIPE = 2) where the geometry allows it (halo_geometry).  FGDM_IGEMM_HALO=0: A/B knob
     static const bool halo_on = !(getenv("FGDM_IGEMM_HALO") && atoi(getenv("FGDM_IGEMM_HALO")) == 0);
     const bool halo = halo_on && pipe && halo_geometry(a);

@@ -401,10 +401,13 @@ def test_attention_logit_ranges_d40(lib, gain, shift):
 # M, K1, C, N2, act2 (0 / 3 = GEGLU), resid, forced tile cfg (0 = automatic), expected partial-sum slots per row (< 0: from
 # the separate row-statistics pass instead of the producing GEMM's epilogue)
 LN_CASES = [
-    (16384, 320, 320, 640, 0, True, 0, 2),      # 128x320 pipelined tiles: statistics from the producer's epilogue (2 slots)
+    (32768, 320, 320, 640, 0, True, 0, 2),      # 128x320 pipelined tiles: statistics from the producer's epilogue (2 slots)
+    (16384, 320, 320, 640, 0, True, 0, -2),     # 128 tiles of 128x320 would fill half the chip: 64x160 four-wave tiles (round 4),
+                                                # which cannot emit the statistics -> the separate pass (same 2 slots, same bits)
     (65536, 320, 320, 2560, 3, True, 0, 2),     # 256x320 producer, GEGLU consumer on 256x256 tiles
     (8192, 1280, 1280, 1280, 0, True, 0, 8),    # 8 slots per row
-    (8192, 640, 640, 5120, 3, False, 0, 4),
+    (8192, 640, 640, 5120, 3, False, 0, -4),    # producer: 64x160 tiles + the separate pass (128 tiles of 128x320 = half the chip); consumer: persistent GEGLU kernel
+    (32768, 640, 640, 5120, 3, False, 0, 4),    # producer on 128x320 tiles: 4 slots from its epilogue
     (200, 320, 320, 320, 0, True, 0, -2),       # small problem: 2-stage kernel + the separate row-statistics pass (same 2 slots)
     (16384, 320, 320, 640, 0, True, 1, -2),     # the same shape as case 0 forced onto the 2-stage kernel
     (4100, 640, 640, 640, 0, False, 6, 4),      # ragged M on the 128x320 tiles
