@@ -884,7 +884,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm2_pair_kernel(const IgemmAr
 // (same K order, same MFMA, same ln_scale / gelu2_f / roundings): the output does not change by a bit.
 // Only what that layer needs: LINEAR, one source, fp16 row-major output, no emb row, no residual, no second destination.
 template <bool LN>
-__global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmArgs a, int ntiles) {
+__global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmArgs a, int ntiles, int contiguous) {
     constexpr int BM = 256, BN = 256, WM = 4, WN = 2, NW = 8, T = 512, STAGES = 4, MS = 16;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / MS, NI = TN / MS, AR = 4;
     typedef float acc_t __attribute__((ext_vector_type(AR)));
@@ -899,12 +899,19 @@ __global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmAr
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = a.N / BN;
     const int nk = a.K >> 5;
-    // tiles of this workgroup: XCD x = blockIdx & 7 owns a contiguous range of logical tiles (as in igemm2_kernel), its gridDim / 8
-    // workgroups take them round-robin
+    // tiles of this workgroup: XCD x = blockIdx & 7 owns a contiguous range of logical tiles (as in igemm2_kernel), and each of its
+    // gridDim / 8 workgroups a contiguous RUN of that range: consecutive tiles of a run are column tiles of the same 256 rows, so the
+    // rows' LayerNorm (mean, rstd) -- double-precision arithmetic per row -- are formed once per row block, not once per tile
     const int xcd = blockIdx.x & 7, G8 = gridDim.x >> 3, tq = ntiles >> 3, tr = ntiles & 7;
-    const int t_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, t_count = tq + (xcd < tr ? 1 : 0);
-    int local = blockIdx.x >> 3;
-    if (local >= t_count) return;
+    const int x_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, x_count = tq + (xcd < tr ? 1 : 0);
+    // (contiguous = 0: round-robin instead -- at any moment the workgroups of an XCD then sit on ~3 row blocks and share their X
+    // tiles through the L2, where contiguous runs keep 32 different X tiles per XCD in flight)
+    const int per = (x_count + G8 - 1) / G8, jw = blockIdx.x >> 3;
+    const int t_first = contiguous ? x_first + jw * per : x_first + jw;
+    const int t_count = contiguous ? min(per, x_count - jw * per) : (x_count - jw + G8 - 1) / G8;
+    const int t_step = contiguous ? 1 : G8;
+    int local = 0;
+    if (t_count <= 0) return;
 
     const int lrow = lane & (MS - 1), lh = lane / MS, lq = 4 * lh;
     const int koff = lrow * ROWB + ((lh ^ swz_of(lrow)) << 4);
@@ -935,11 +942,15 @@ __global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmAr
         for (int p2 = 0; p2 < LB; ++p2) glds16_sv(b_b[p2], wbase, lbase + (unsigned)b_lds[p2]);
     };
     float* const ops = (float*)(smem + RING_BYTES);
-    auto stage_ops = [&](int m0x, int n0x, int set) {        // epilogue operands of a tile -> LDS set `set`
+    auto stage_ops = [&](int m0x, int n0x, int set, bool same_rows) {      // epilogue operands of a tile -> LDS set `set`
         float* bias_l = ops + set * OPS_FLOATS, *mr_l = bias_l + BN, *u_l = mr_l + 2 * BM;
         for (int c = tid; c < BN; c += T) bias_l[c] = a.bias ? a.bias[n0x + c] : 0.f;
         if constexpr (LN) {
             for (int c = tid; c < BN; c += T) u_l[c] = a.ln_u[n0x + c];
+            if (same_rows) {             // the previous tile of this run had the same rows: copy its (mean, rstd) from the other set
+                const float* prev = ops + (set ^ 1) * OPS_FLOATS + BN;
+                for (int r = tid; r < 2 * BM; r += T) mr_l[r] = prev[r];
+            } else
             for (int r = tid; r < BM; r += T) {      // partial sums in fixed slot order; E[x^2] - mean^2 in double (as igemm2_kernel)
                 float mean = 0.f, rstd = 0.f;
                 if (m0x + r < a.M) {
@@ -957,13 +968,13 @@ __global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmAr
         }
     };
 
-    int logical = t_first + local;
+    int logical = t_first;
     int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
     setup(m0, n0);
 #pragma unroll
     for (int sg = 0; sg < STAGES - 1; ++sg)
         if (sg < nk) issue_stage(sg);
-    stage_ops(m0, n0, 0);
+    stage_ops(m0, n0, 0, false);
     int set = 0;
     bool first = true;
     for (;;) {
@@ -1045,11 +1056,11 @@ __global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmAr
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // all waves are out of the K loop: the ring is free
         // ---- the next tile's first two stages start their trip now (ring slots 0, 1; the epilogue stages through slots 2, 3)
-        local += G8;
+        local += 1;
         const bool more = local < t_count;
         const int m0c = m0, n0c = n0;
         if (more) {
-            logical = t_first + local;
+            logical = t_first + local * t_step;
             m0 = (logical / ntn) * BM; n0 = (logical % ntn) * BN;
             setup(m0, n0);
             if (nk > 0) issue_stage(0);
@@ -1118,7 +1129,7 @@ __global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmAr
         // ---- the next tile's epilogue operands (other LDS set), then -- behind a barrier: every wave is out of the staging
         // slots -- its third stage
         set ^= 1;
-        stage_ops(m0, n0, set);
+        stage_ops(m0, n0, set, m0 == m0c);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (nk > 2) issue_stage(2);
@@ -1127,7 +1138,7 @@ __global__ __launch_bounds__(512) void igemm2_geglu_persist_kernel(const IgemmAr
 }
 
 template <bool LN>
-int launch_geglu_persist(const IgemmArgs& a, int ntiles, hipStream_t s) {
+int launch_geglu_persist(const IgemmArgs& a, int ntiles, int contiguous, hipStream_t s) {
     constexpr int smem = 4 * (256 + 256) * ROWB + 2 * (256 + 2 * 256 + 256) * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
@@ -1136,7 +1147,7 @@ int launch_geglu_persist(const IgemmArgs& a, int ntiles, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    FGDM_LAUNCH(k, dim3(256), dim3(512), smem, s, a, ntiles);
+    FGDM_LAUNCH(k, dim3(256), dim3(512), smem, s, a, ntiles, contiguous);
     return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
 }
 
@@ -1347,11 +1358,12 @@ int igemm2_launch(const IgemmArgs& a, int cfg, hipStream_t s) {
     if (a.ln_stats && a.mode != IG_LINEAR) return FGDM_ERR_ARG;
     // the persistent GEGLU projection (igemm2_geglu_persist_kernel): 256 workgroups walk the tiles once there are more tiles than
     // CUs.  FGDM_IGEMM_PERSIST=0: A/B knob (the outputs are bit-identical either way)
-    static const bool persist_on = !(getenv("FGDM_IGEMM_PERSIST") && atoi(getenv("FGDM_IGEMM_PERSIST")) == 0);
+    static const int persist_mode = getenv("FGDM_IGEMM_PERSIST") ? atoi(getenv("FGDM_IGEMM_PERSIST")) : 1;      // 1 = round-robin tiles, 2 = contiguous runs
+    const bool persist_on = persist_mode != 0;
     if (persist_on && tile == 1 && pipe && a.act == ACT_GEGLU && a.mode == IG_LINEAR && !a.C1 && a.out_kind == OUT_F16 && !a.rowvec &&
         !a.resid && !a.out2 && !a.stats_out && !a.debug && a.N % 256 == 0) {
         const int ntiles = ((a.M + 255) / 256) * (a.N / 256);
-        if (ntiles > 256) return a.ln_stats ? launch_geglu_persist<true>(a, ntiles, s) : launch_geglu_persist<false>(a, ntiles, s);
+        if (ntiles > 256) return a.ln_stats ? launch_geglu_persist<true>(a, ntiles, persist_mode == 2, s) : launch_geglu_persist<false>(a, ntiles, persist_mode == 2, s);
     }
     // the halo loop (PIPE = 2) where the geometry allows it (halo_geometry).  FGDM_IGEMM_HALO=0: A/B knob
     static const bool halo_on = !(getenv("FGDM_IGEMM_HALO") && atoi(getenv("FGDM_IGEMM_HALO")) == 0);
