@@ -144,6 +144,31 @@ def test_linear_variants(lib):
         assert float(outT[:, :, rps:].abs().max()) == 0.0 if ld > rps else True
 
 
+@pytest.mark.parametrize('M,K,N', [(66000, 320, 2560), (16500, 640, 5120)], ids=['L0-like ragged M', 'L1-like ragged M'])
+def test_geglu_persistent_kernel(lib, M, K, N):
+    """The GEGLU projection (ldm/modules/attention.py:37-64) with more 256 x 256 tiles than CUs runs on the persistent kernel
+    (igemm2_geglu_persist_kernel, round 4): 256 workgroups walk the tiles, the next tile's first stages travel behind the current
+    epilogue.  Without a folded LayerNorm here (the LayerNorm-folded form is held bitwise against the 2-stage kernel by
+    test_layernorm_folded_into_consumer_gemm); M is not a multiple of 256, so the last row tile of every column is ragged, and the
+    same call forced onto the one-workgroup-per-tile kernels (phase-locked loop) must give the same bits."""
+    x = h16(rnd((M, K), 21))
+    w = h16(rnd((N, K), 22, 1 / np.sqrt(K)))
+    b = rnd((N,), 23, 0.1)
+    a, g = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    xd, wd, bd = x.half().cuda(), w.cuda(), b.cuda()
+    out = torch.empty(M, N // 2, dtype=torch.half, device='cuda')
+    assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), None, M, K, N, 3, 0, 0, 0, _p(out), _st()) == 0
+    assert relerr(out.float().cpu(), ref) < TOL
+    out2 = torch.empty_like(out)
+    try:
+        lib.fgdm_debug_force_igemm_cfg(5 + 16)          # 256 x 256 tiles, phase-locked K loop: never the persistent kernel
+        assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), None, M, K, N, 3, 0, 0, 0, _p(out2), _st()) == 0
+    finally:
+        lib.fgdm_debug_force_igemm_cfg(0)
+    assert torch.equal(out, out2)
+
+
 GN_CASES = [(2, 64, 320, 0, 1e-5, 1), (2, 64, 1280, 640, 1e-5, 1), (1, 16, 1280, 1280, 1e-5, 1),
             (2, 1, 1280, 0, 1e-6, 0), (3, 4096, 320, 0, 1e-6, 0), (2, 256, 640, 320, 1e-5, 1),
             # 82 KB slices (two-kernel path since round 2), a 41 KB slice (single kernel, second choice), ragged pixel counts,
@@ -408,6 +433,7 @@ LN_CASES = [
     (8192, 1280, 1280, 1280, 0, True, 0, 8),    # 8 slots per row
     (8192, 640, 640, 5120, 3, False, 0, -4),    # producer: 64x160 tiles + the separate pass (128 tiles of 128x320 = half the chip); consumer: persistent GEGLU kernel
     (32768, 640, 640, 5120, 3, False, 0, 4),    # producer on 128x320 tiles: 4 slots from its epilogue
+    (16500, 640, 640, 5120, 3, True, 0, 4),     # ragged M through the persistent GEGLU kernel (65 row tiles x 20 column tiles)
     (200, 320, 320, 320, 0, True, 0, -2),       # small problem: 2-stage kernel + the separate row-statistics pass (same 2 slots)
     (16384, 320, 320, 640, 0, True, 1, -2),     # the same shape as case 0 forced onto the 2-stage kernel
     (4100, 640, 640, 640, 0, False, 6, 4),      # ragged M on the 128x320 tiles
