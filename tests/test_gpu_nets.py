@@ -257,6 +257,29 @@ def test_non_square_latent_and_batch_one_vs_oracle(small_engine):
                         lambda: onn.control_ldm_apply(p, cfg, x, t, ctx, [hint], scales=gi.CTRL_SCALES))
 
 
+def test_latent_96x96_vs_oracle(small_engine):
+    """A 768x768 image (96x96 latent): the attention query-block count is not a power of two (T = 9216 and 2304), 96 and 48 wide
+    feature maps take the per-tap conv loop rather than the halo one -- against the oracle."""
+    from oracle import arch, nn as onn
+    cfg = gi.SMALL_CFG
+    x = torch.from_numpy(synth.latents(1, 96, 96, seed=41))
+    ctx = torch.from_numpy(synth.context(1, seed=42))
+    h = torch.from_numpy(synth.hint(1, res=256, seed=43))
+    hint = torch.cat([torch.cat([h, h.flip(-1), h], dim=-1), torch.cat([h.flip(-2), h, h.flip(-1)], dim=-1),
+                      torch.cat([h, h.flip(-2), h], dim=-1)], dim=-2).contiguous()          # 768 x 768
+    t = torch.tensor([301])
+    small_engine.set_hint(0, hint.cuda())
+    got = small_engine.apply_model(x, t, ctx, control_scales=gi.CTRL_SCALES)
+    p = {}
+    for pre, name, shapes in (('model.diffusion_model.', 'small.', arch.unet_param_shapes(cfg, adapter=False)),
+                              ('control_model.', 'small_cn.', arch.controlnet_param_shapes(cfg))):
+        for k, s in shapes.items():
+            p[pre + k] = torch.from_numpy(synth.make_tensor(name + k, s))
+    assert tuple(got.shape) == (1, 4, 96, 96)
+    check_net_vs_oracle('96x96 latent, batch 1, UNet+ControlNet', got.cpu(),
+                        lambda: onn.control_ldm_apply(p, cfg, x, t, ctx, [hint], scales=gi.CTRL_SCALES))
+
+
 @pytest.mark.parametrize('ncn,width', [(2, 'reduced'), (3, 'reduced')])
 def test_several_controlnets_sum_of_residuals_vs_oracle(ncn, width):
     """BASELINE configs 4 (seg + depth) and 5 (seg + depth + normal): several ControlNets on one UNet.  Not in the reference
