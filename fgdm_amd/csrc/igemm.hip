@@ -363,13 +363,15 @@ static int pick_force(const IgemmArgs& a) {
 }
 
 // Will igemm_launch(a) write LayerNorm partial sums into a.stats_out, and how many slots per row?  Only the pipelined
-// kernel's 320-column tiles do (two 160-column wave tiles each); otherwise 0 and the caller runs row_stats_launch.
+// kernel's 320-column tiles (two 160-column wave tiles each) and its 64 x 160 tile do; otherwise 0 and the caller runs row_stats_launch.
 int igemm_stats_slots(const IgemmArgs& a) {
     if (a.out_kind != OUT_F16 || a.act == ACT_GEGLU || a.splitk > 1 || (a.N % 320) || (a.K & 31) || (a.C0 & 31) || (a.C1 & 31)) return 0;
     const int f = pick_force(a);
     if (f < 4) return 0;
     const int tile = (f - 4) & 15;
-    return (tile == 0 || tile == 2 || tile == 3 || tile == 5) ? a.N / 160 : 0;
+    // (tile 7, 64 x 160: its two 80-column waves per row meet in LDS and write the same 160-column slots)
+    static const bool stats64 = !(getenv("FGDM_IGEMM_STATS64") && atoi(getenv("FGDM_IGEMM_STATS64")) == 0);       // A/B knob (same bits either way)
+    return (tile == 0 || tile == 2 || tile == 3 || tile == 5 || (tile == 7 && stats64)) ? a.N / 160 : 0;
 }
 
 int igemm_launch(const IgemmArgs& a, hipStream_t s) {

@@ -816,7 +816,9 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
                 }
             }
             bool want_stats = false;
-            if constexpr (OUT_TN == 160) want_stats = a.stats_out != nullptr;
+            // 160-column wave tiles own a whole slot; the 64 x 160 tile's two 80-column waves of a row meet in LDS below (HALF)
+            constexpr bool HALF = OUT_TN == 80 && WN == 2 && TM == 32 && !GEGLU;
+            if constexpr (OUT_TN == 160 || HALF) want_stats = a.stats_out != nullptr;
             float* tab = (float*)cst;                            // [32][CPR][2], over the (by then dead) staging tile
             if (want_stats) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every staging read has landed
 #pragma unroll
@@ -842,6 +844,27 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgs& a) {
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next pass overwrites
+            if constexpr (HALF) {
+                if (want_stats) {        // (block-uniform)
+                    // the slot's 20 chunks in the SAME order of additions as everywhere else (row_stats_kernel): the left wave adds
+                    // its ten, then the right wave's ten from that wave's table
+                    __builtin_amdgcn_s_barrier();
+                    if (wn == 0 && lane < 32) {
+                        const float* tab1 = (const float*)(smem + (wave + 1) * CST_BYTES);
+                        const int grow = m0 + wm * TM + ip * 32 + lane;
+                        float sm = 0.f, sq = 0.f;
+#pragma unroll
+                        for (int k = 0; k < CPR; ++k) { sm += tab[2 * (lane * CPR + k)]; sq += tab[2 * (lane * CPR + k) + 1]; }
+#pragma unroll
+                        for (int k = 0; k < CPR; ++k) { sm += tab1[2 * (lane * CPR + k)]; sq += tab1[2 * (lane * CPR + k) + 1]; }
+                        if (grow < a.M) {
+                            float* dst = a.stats_out + ((size_t)grow * (a.N / 160) + n0 / 160) * 2;
+                            dst[0] = sm; dst[1] = sq;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            } else
             if (want_stats) {
                 // one lane per row adds the row's CPR chunks in fixed order -> slot (n0 + wn * TN) / 160 of stats_out
                 if (lane < 32) {

@@ -427,18 +427,19 @@ def test_attention_logit_ranges_d40(lib, gain, shift):
 # the separate row-statistics pass instead of the producing GEMM's epilogue)
 LN_CASES = [
     (32768, 320, 320, 640, 0, True, 0, 2),      # 128x320 pipelined tiles: statistics from the producer's epilogue (2 slots)
-    (16384, 320, 320, 640, 0, True, 0, -2),     # 128 tiles of 128x320 would fill half the chip: 64x160 four-wave tiles (round 4),
-                                                # which cannot emit the statistics -> the separate pass (same 2 slots, same bits)
+    (16384, 320, 320, 640, 0, True, 0, 2),      # 128 tiles of 128x320 would fill half the chip: 64x160 four-wave tiles (round 4); the two
+                                                # 80-column waves of a row meet in LDS and write the same 160-column slots, same bits
     (65536, 320, 320, 2560, 3, True, 0, 2),     # 256x320 producer, GEGLU consumer on 256x256 tiles
     (8192, 1280, 1280, 1280, 0, True, 0, 8),    # 8 slots per row
-    (8192, 640, 640, 5120, 3, False, 0, -4),    # producer: 64x160 tiles + the separate pass (128 tiles of 128x320 = half the chip); consumer: persistent GEGLU kernel
+    (8192, 640, 640, 5120, 3, False, 0, 4),     # producer: 64x160 tiles (128 tiles of 128x320 = half the chip); consumer: persistent GEGLU kernel
     (32768, 640, 640, 5120, 3, False, 0, 4),    # producer on 128x320 tiles: 4 slots from its epilogue
     (16500, 640, 640, 5120, 3, True, 0, 4),     # ragged M through the persistent GEGLU kernel (65 row tiles x 20 column tiles)
     (200, 320, 320, 320, 0, True, 0, -2),       # small problem: 2-stage kernel + the separate row-statistics pass (same 2 slots)
     (16384, 320, 320, 640, 0, True, 1, -2),     # the same shape as case 0 forced onto the 2-stage kernel
     (4100, 640, 640, 640, 0, False, 6, 4),      # ragged M on the 128x320 tiles
     (8192, 1280, 1280, 3840, 0, True, 0, 8),    # the 16x16 level's q|k|v width: 256x256 tiles divide the chip better (automatic)
-    (2048, 1280, 1280, 1280, 0, True, 0, -8),   # the 8x8 level: 64x160 four-wave tiles (automatic), statistics from the separate pass
+    (2048, 1280, 1280, 1280, 0, True, 0, 8),    # the 8x8 level: 64x160 four-wave tiles (automatic), statistics from their epilogue
+    (4100, 1280, 1280, 1280, 0, True, 0, 8),    # ragged M on the 64x160 tiles (the 16x16 level at 8 prompts per GPU, plus four rows)
 ]
 
 
