@@ -346,7 +346,12 @@ static int pick_force(const IgemmArgs& a) {
             static const bool small_m = !(getenv("FGDM_IGEMM_SMALL_M") && atoi(getenv("FGDM_IGEMM_SMALL_M")) == 0);              // A/B knob
             const bool lin64 = a.mode == IG_LINEAR && !(a.K & 31) && !(a.C0 & 31) && !(a.C1 & 31) && small_tiles;
             const long b64 = (long)((a.M + 63) / 64) * (a.N / 160);
+            // ... except the long-K ones among them (the 16x16 level's feed-forward output, K = 5120, at 8 prompts per GPU): 64 x 160 tiles
+            // move too many L2 -> LDS bytes per FLOP there; 160 tiles of 256 x 128 run it in 79 us (64 x 160: 95, 128 x 320: 86)
+            const long b256n = (long)((a.M + 255) / 256) * (a.N / 128);
             if (b256 * g_pair_mult >= 192) force = 4;
+            else if (small_m && lin64 && a.K >= 2560 && !(a.N % 128) && !a.ln_stats && !a.stats_out && !a.out2 && b128 >= 96 && b128 * g_pair_mult < 192 &&
+                     b64 >= 512 && b256n >= 144 && b256n <= 256) force = 10;
             else if (b128 >= 96 && !(small_m && lin64 && b128 * g_pair_mult < 192 && b64 >= 512)) force = 6;
             else if (lin64 && b64 >= 128) force = 11;
         } else if (geglu && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= 128) {

@@ -340,6 +340,30 @@ def test_conv_pipelined_kernel(lib, case):
         lib.fgdm_debug_force_igemm_cfg(0)
 
 
+def test_long_k_linear_at_8_prompts_same_bits_on_every_tile(lib):
+    """The 16x16 level's feed-forward output at 8 prompts per GPU (M = 4096, K = 5120 -> 1280, + residual; attention.py:53-64): the
+    automatic choice (256x128 tiles, round 4) against torch, and bit for bit against 128x320, 64x160 and the 2-stage kernel --
+    which tile runs depends on the batch, a sample's result must not."""
+    M, K, N = 4100, 5120, 1280
+    x = h16(rnd((M, K), 91))
+    w, b = h16(rnd((N, K), 92, 1 / np.sqrt(K))), rnd((N,), 93, 0.1)
+    res = h16(rnd((M, N), 94))
+    xd, wd, bd, rd = x.half().cuda(), w.cuda(), b.cuda(), res.half().cuda()
+    ref = h16(h16(F.linear(x, w, b)) + res)
+    outs = {}
+    try:
+        for cfg in (0, 6, 10, 11, 1):
+            lib.fgdm_debug_force_igemm_cfg(cfg)
+            out = torch.empty(M, N, dtype=torch.half, device='cuda')
+            assert lib.fgdm_op_linear(_p(xd), _p(wd), _p(bd), _p(rd), M, K, N, 0, 0, 0, 0, _p(out), _st()) == 0
+            assert relerr(out.float().cpu(), ref) < TOL, cfg
+            outs[cfg] = out
+    finally:
+        lib.fgdm_debug_force_igemm_cfg(0)
+    for cfg in (6, 10, 11, 1):
+        assert torch.equal(outs[0], outs[cfg]), f'automatic tile and cfg {cfg} differ'
+
+
 def test_linear_pipelined_kernel(lib):
     try:
         M, K = 300, 320
