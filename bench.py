@@ -151,9 +151,10 @@ def main():
                     help='control models per UNet (1 = the metric\'s config C3; 2 / 3 = BASELINE configs C4 / C5, use --prompts 8; 0 = the plain UNet, C2)')
     ap.add_argument('--no-first-stage', action='store_true',
                     help='skip the VAE decode that follows the timed region (PMC passes: counters then cover the path only)')
-    ap.add_argument('--profile-stride', type=int, default=7,
+    ap.add_argument('--profile-stride', type=int, default=31,
                     help='HIP-event bracket every n-th kernel launch of the timed region (coprime with the 830 launches per '
-                         'evaluation, so every layer shape is sampled uniformly); 1 = every launch')
+                         'evaluation, so every layer shape is sampled uniformly); 1 = every launch.  Two event packets leave a ~6 us '
+                         'hole in the queue: at stride 7 they cost 0.3-0.8 %% of the step (profiles/r04_ab_profile_stride.txt)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend: nccl (= RCCL over xGMI, the product) or gloo (CPU rehearsal with --dry-run)')
     ap.add_argument('--twin-streams', action='store_true',

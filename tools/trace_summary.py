@@ -52,6 +52,17 @@ def main():
     big = [int(i) for i in np.nonzero(gaps > 20000)[0][:40]]
     big_list = [{'gap_us': float(gaps[i]) / 1e3, 'after': rows[i][2][:60], 'before': rows[i + 1][2][:60],
                  'kernel_index': i} for i in big]
+    # who sits on either side of the small gaps (2 us .. 20 us)?  total gap time by the kernel that starts after the gap
+    def short(n):
+        n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+        return n.split('(')[0][:70]
+    by_next, by_prev = {}, {}
+    for i in np.nonzero((gaps > 2000) & (gaps <= 20000))[0]:
+        for d, k in ((by_next, short(rows[i + 1][2])), (by_prev, short(rows[i][2]))):
+            v = d.setdefault(k, [0, 0])
+            v[0] += 1
+            v[1] += int(gaps[i])
+    top = lambda d: [{'kernel': k, 'gaps': v[0], 'ms': v[1] / 1e6} for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])[:12]]
     res = {
         'window': f'last sampling pass: kernels {first}..{last} of the trace ({nsteps} k_ddim_step launches; decode excluded)',
         'kernels': len(rows), 'span_ms': span / 1e6, 'kernel_sum_ms': float(dur.sum()) / 1e6,
@@ -61,6 +72,7 @@ def main():
         'gap_p99_us': float(np.percentile(gaps, 99)) / 1e3, 'gaps_over_20us': int((gaps > 20000).sum()),
         'gap_ms_in_gaps_over_20us': float(gaps[gaps > 20000].sum()) / 1e6,
         'big_gaps': big_list,
+        'small_gaps_by_following_kernel': top(by_next), 'small_gaps_by_preceding_kernel': top(by_prev),
         'families': {k: {'launches': v[0], 'ms': v[1] / 1e6, 'avg_us': v[1] / v[0] / 1e3} for k, v in fam.items()},
     }
     json.dump(res, open(out, 'w'), indent=1)
