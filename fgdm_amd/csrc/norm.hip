@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cstdlib>
 
-#define GN_PIX_PER_CHUNK 64
+// pixels per partial-sum chunk of the two-kernel path (round 4: 64 -> 256, the reduction tail of a stats workgroup was as long as its
+// loads: 64x64 x 320 channels, B = 32: 50.1 -> 45.5 us for both kernels, B = 16: 32.1 -> 29.3; profiles/r04_gn_chunk.txt)
+#define GN_PIX_PER_CHUNK 256
 
 __device__ __forceinline__ const half_t* src_octet(const half_t* x0, int C0, const half_t* x1, int C1,
                                                    size_t pix, int o) {
@@ -423,7 +425,10 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
         }
     }
     { const int rc = try_reg(); if (rc != 1) return rc; }
-    const int ppc = GN_PIX_PER_CHUNK;
+    // pixels per partial-sum chunk of the two-kernel path: a constant of the build (a sample's bits must not depend on it varying);
+    // FGDM_GN_CHUNK is a tuning knob for experiments (multiples of 64, so that the workspace bound above holds)
+    static const int ppc_env = getenv("FGDM_GN_CHUNK") ? atoi(getenv("FGDM_GN_CHUNK")) : GN_PIX_PER_CHUNK;
+    const int ppc = (ppc_env >= 64 && ppc_env % 64 == 0) ? ppc_env : GN_PIX_PER_CHUNK;
     const int nchunk = (HW + ppc - 1) / ppc;
     float* partial = ws;
     const int P = C >> 3, PI = P <= 256 ? 256 / P : 1;
