@@ -951,7 +951,9 @@ struct fgdm_engine {
         if (taps * (a.C0 + a.C1) != a.K) return fail(FGDM_ERR_ARG, "gemm: K mismatch");
         if (!a.out) return fail(FGDM_ERR_NOMEM, "gemm: null output (workspace exhausted?)");
         char tag[56] = "";
-        if (prof.on) snprintf(tag, sizeof(tag), "igemm M%d N%d K%d mode%d act%d out%d", a.M, a.N, a.K, a.mode, a.act, a.out_kind);
+        // (l: LayerNorm folded in, s: emits LayerNorm partial sums, r: residual, v: per-sample emb row)
+        if (prof.on) snprintf(tag, sizeof(tag), "igemm M%d N%d K%d mode%d act%d out%d l%ds%dr%dv%d", a.M, a.N, a.K, a.mode, a.act, a.out_kind,
+                              e.ln ? 1 : 0, e.stats ? 1 : 0, e.resid ? 1 : 0, e.rowvec ? 1 : 0);
         a.splitk = igemm_splitk_factor(a);
         if (a.splitk > 1) {
             a.ws = (float*)ar->alloc((size_t)a.splitk * a.M * a.N * sizeof(float));
