@@ -464,6 +464,7 @@ LN_CASES = [
     (8192, 1280, 1280, 3840, 0, True, 0, 8),    # the 16x16 level's q|k|v width: 256x256 tiles divide the chip better (automatic)
     (2048, 1280, 1280, 1280, 0, True, 0, 8),    # the 8x8 level: 64x160 four-wave tiles (automatic), statistics from their epilogue
     (4100, 1280, 1280, 1280, 0, True, 0, 8),    # ragged M on the 64x160 tiles (the 16x16 level at 8 prompts per GPU, plus four rows)
+    (2050, 1280, 1280, 1280, 0, True, 27, 8),   # the 64x160 tile on the phase-locked K loop emits them the same way
 ]
 
 
