@@ -122,6 +122,7 @@ size_t igemm_npad(int n);   // rows the packed weight must provide
 
 // ---------------------------------------------------------------- norms
 // GroupNorm(32 groups) over NHWC fp16, optionally over the virtual concat of two sources; fp32 statistics.
+void groupnorm_set_group(bool on);     // while the engine records: attach the grouped form to single-pass GroupNorm launches (default on)
 int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, int HW,
                      const float* gamma, const float* beta, float eps, int silu,
                      half_t* out, float* ws /* >= B*32*2*(chunks+1) floats */, hipStream_t s);
@@ -185,6 +186,12 @@ typedef int (*IgemmGroupFn)(const IgemmArgs* const* a, int n, unsigned grid_x, h
 bool fgdm_recording();
 void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key = nullptr, IgemmGroupFn pair = nullptr,
                  const IgemmArgs* ia = nullptr, unsigned grid_x = 0);
+// ... and the same for other kernels with twins (round 4, late: the single-pass GroupNorm kernels): a generic group function gets the
+// problems' argument blobs (<= FGDM_GROUP_BLOB bytes each, copied at record time); launches are matched by key, grid and a shape hash
+#define FGDM_GROUP_BLOB 96
+typedef int (*GenericGroupFn)(const void* const* args, int n, unsigned grid_x, hipStream_t s);
+void fgdm_record_generic(std::function<int(hipStream_t)> run, const void* key, GenericGroupFn fn, const void* args, size_t nbytes,
+                         unsigned grid_x, unsigned long long shape);
 #define FGDM_LAUNCH(kernel, grid, block, smem, stream, ...)                                                                  \
     do {                                                                                                                     \
         if (fgdm_recording()) {                                                                                              \

@@ -189,6 +189,9 @@ struct RecOp {
     IgemmGroupFn pair = nullptr;
     IgemmArgs ia{};
     unsigned grid_x = 0;
+    GenericGroupFn gfn = nullptr;        // ... or of another kernel with a grouped form (GroupNorm): key in pair_key, arguments in gargs
+    unsigned long long gshape = 0;
+    alignas(8) char gargs[FGDM_GROUP_BLOB] = {0};
     int cls = 0;                         // PROF_BEGIN
     double w = 0, bytes = 0;
     char tag[56] = {0};
@@ -260,6 +263,17 @@ void fgdm_record(std::function<int(hipStream_t)> run, const void* pair_key, Igem
     g_rec->push_back(std::move(o));
 }
 
+void fgdm_record_generic(std::function<int(hipStream_t)> run, const void* key, GenericGroupFn fn, const void* args, size_t nbytes,
+                         unsigned grid_x, unsigned long long shape) {
+    RecOp o;
+    o.run = std::move(run);
+    if (fn && args && nbytes <= FGDM_GROUP_BLOB) {
+        o.pair_key = key; o.gfn = fn; o.grid_x = grid_x; o.gshape = shape;
+        memcpy(o.gargs, args, nbytes);
+    }
+    g_rec->push_back(std::move(o));
+}
+
 #define CHK0(x) do { int _rc0 = (x); if (_rc0 != FGDM_OK) return _rc0; } while (0)
 struct fgdm_engine {
     fgdm_config cfg{};
@@ -302,6 +316,7 @@ struct fgdm_engine {
     // launches") and replayed in lockstep on the one stream, twin GEMM launches fused into grouped launches (replay_zip)
     bool pair_launch = true;
     int group_max = FGDM_MAX_GROUP;      // FGDM_GROUP_MAX (read at fgdm_create): 2 = round 3's pairwise replay; the A/B knob
+    bool gn_group = true;                // FGDM_GN_GROUP (read at fgdm_create): the twins' single-pass GroupNorm launches group too
     long paired_launches = 0, replayed_launches = 0, paired_problems = 0;      // fused launches; all replayed launches; problems in fused launches
     struct Deferred { const GemmW* w; Tensor src; int idx; float scale; Arena* owner; };
     Prof prof;
@@ -1490,8 +1505,8 @@ struct fgdm_engine {
     struct Unit { size_t first, last; long launch; };
     static Unit unit_at(std::vector<RecOp>& v, size_t i) {
         if (v[i].kind == RecOp::PROF_BEGIN && i + 2 < v.size() + 0 && v[i + 1].kind == RecOp::RUN && v[i + 2].kind == RecOp::PROF_END)
-            return Unit{i, i + 2, v[i + 1].pair ? (long)(i + 1) : -1};
-        if (v[i].kind == RecOp::RUN) return Unit{i, i, v[i].pair ? (long)i : -1};
+            return Unit{i, i + 2, (v[i + 1].pair || v[i + 1].gfn) ? (long)(i + 1) : -1};
+        if (v[i].kind == RecOp::RUN) return Unit{i, i, (v[i].pair || v[i].gfn) ? (long)i : -1};
         return Unit{i, i, -1};
     }
     int run_unit(std::vector<RecOp>& v, const Unit& u) {
@@ -1524,7 +1539,8 @@ struct fgdm_engine {
                         size_t jj = at[m];
                         for (int d = 0; d < LOOK && jj < B.size(); ++d) {
                             const Unit u = unit_at(B, jj);
-                            if (u.launch >= 0 && B[u.launch].pair_key == A[ua.launch].pair_key && B[u.launch].grid_x == A[ua.launch].grid_x) {
+                            if (u.launch >= 0 && B[u.launch].pair_key == A[ua.launch].pair_key && B[u.launch].grid_x == A[ua.launch].grid_x &&
+                                B[u.launch].gshape == A[ua.launch].gshape) {
                                 who[n] = m; un[n++] = u;
                                 break;
                             }
@@ -1540,15 +1556,18 @@ struct fgdm_engine {
                 }
                 // fused: one bracket (all the problems' work), one launch
                 const IgemmArgs* av[FGDM_MAX_GROUP];
+                const void* gv[FGDM_MAX_GROUP];
                 double w = 0.0, bytes = 0.0;
                 const RecOp* br = nullptr;
                 for (int k = 0; k < n; ++k) {
                     std::vector<RecOp>& B = *L[who[k]];
                     av[k] = &B[un[k].launch].ia;
+                    gv[k] = B[un[k].launch].gargs;
                     if (un[k].first != un[k].last) { w += B[un[k].first].w; bytes += B[un[k].first].bytes; if (!br) br = &B[un[k].first]; }
                 }
                 if (br) prof.begin(br->cls, s, w, br->tag, bytes);
-                CHK(A[ua.launch].pair(av, n, A[ua.launch].grid_x, s));
+                if (A[ua.launch].pair) CHK(A[ua.launch].pair(av, n, A[ua.launch].grid_x, s));
+                else CHK(A[ua.launch].gfn(gv, n, A[ua.launch].grid_x, s));
                 if (br) prof.end(s);
                 ++paired_launches; ++replayed_launches; paired_problems += n;
                 for (int k = 0; k < n; ++k) at[who[k]] = un[k].last + 1;
@@ -1687,6 +1706,7 @@ struct fgdm_engine {
         if (paired) {
             static const bool fat = !(getenv("FGDM_PAIR_FAT_TILES") && atoi(getenv("FGDM_PAIR_FAT_TILES")) == 0);       // A/B knob
             if (fat) igemm_set_pair_hint(std::min<int>(group_max, 1 + (int)cns.size()));
+            groupnorm_set_group(gn_group);
             int rc = FGDM_OK;
             for (size_t c = 0; c < cns.size() && rc == FGDM_OK; ++c) {
                 ar = cn_arena[c].get();           // an arena per walk: see cn_arena
@@ -2030,6 +2050,7 @@ int fgdm_create(const fgdm_config* cfg, int device, fgdm_engine** out) {
     if (const char* v = getenv("FGDM_TWIN_STREAMS")) e->twin_streams = atoi(v) != 0;
     if (const char* v = getenv("FGDM_PAIR_LAUNCH")) e->pair_launch = atoi(v) != 0;
     if (const char* v = getenv("FGDM_GROUP_MAX")) e->group_max = std::max(2, std::min(FGDM_MAX_GROUP, atoi(v)));
+    if (const char* v = getenv("FGDM_GN_GROUP")) e->gn_group = atoi(v) != 0;
     if (e->twin_streams && !e->cns.empty()) {
         if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||

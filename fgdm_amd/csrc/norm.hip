@@ -7,6 +7,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 // pixels per partial-sum chunk of the two-kernel path (round 4: 64 -> 256, the reduction tail of a stats workgroup was as long as its
 // loads: 64x64 x 320 channels, B = 32: 50.1 -> 45.5 us for both kernels, B = 16: 32.1 -> 29.3; profiles/r04_gn_chunk.txt)
@@ -151,8 +152,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 // sample, keeps that [HW][NG * cpg] slice in LDS (<= 96 KB), so x is read from HBM once instead of twice and the second
 // launch disappears (these calls were latency-bound: 24 us for a 5 MB tensor at the 8x8 level).  Same fixed-order
 // reductions as the two-kernel path -> bitwise independent of the batch.
+// Twin layers (the UNet encoder's and every ControlNet's GroupNorm of the same shape) share ONE launch of the single-pass kernels:
+// blockIdx.y selects the problem (engine.hip: replay_group).  Same bodies -> same bits.
+struct GnProb { const half_t* x0; const half_t* x1; const float* gamma; const float* beta; half_t* out; };
+struct GnArgsG { GnProb p[FGDM_MAX_GROUP]; int C0, C1, B, HW, NG, silu; float eps; };
+struct GnRec { GnProb p; int C0, C1, B, HW, NG, silu; float eps; int np_sel; unsigned smem; };     // what a recorded launch keeps (<= FGDM_GROUP_BLOB)
+static_assert(sizeof(GnRec) <= FGDM_GROUP_BLOB, "GroupNorm record must fit the recorder's blob");
+
 template <int NT>   // threads per workgroup: 256 when 3+ workgroups share a CU, 512 when one 80 KB slice owns it (memory-level parallelism)
-__global__ __launch_bounds__(NT) void gn_fused_kernel(const half_t* __restrict__ x0, int C0,
+__device__ __forceinline__ void gn_fused_body(const half_t* __restrict__ x0, int C0,
                                                         const half_t* __restrict__ x1, int C1, int B, int HW, int NG,
                                                         float eps, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu,
@@ -246,13 +254,25 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const half_t* __restrict__
     }
 }
 
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const half_t* __restrict__ x0, int C0, const half_t* __restrict__ x1, int C1, int B, int HW,
+                                                        int NG, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int silu, half_t* __restrict__ out) {
+    gn_fused_body<NT>(x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_fused_group_kernel(const GnArgsG g) {
+    const GnProb& p = g.p[blockIdx.y];
+    gn_fused_body<NT>(p.x0, g.C0, p.x1, g.C1, g.B, g.HW, g.NG, g.eps, p.gamma, p.beta, g.silu, p.out);
+}
+
 // Large feature maps (the 64x64 / 32x32 levels: a slice of NG whole groups of one sample is 160-330 KB, more than LDS holds): the
 // slice lives in the REGISTERS of one 1024-thread workgroup (NP 16-byte pieces per thread: 84 of the 128 registers a thread has at
 // that occupancy), so x is read once instead of twice and the second launch disappears, exactly as in the kernel above; only the
 // per-channel partial sums go through LDS.  One workgroup per CU; all of them load (every piece requested before the first use), then
 // reduce, then store: HBM sees a pure read phase and a pure write phase.  Same fixed-order reductions -> independent of the batch.
 template <int NP>
-__global__ __launch_bounds__(1024) void gn_reg_kernel(const half_t* __restrict__ x0, int C0,
+__device__ __forceinline__ void gn_reg_body(const half_t* __restrict__ x0, int C0,
                                                       const half_t* __restrict__ x1, int C1, int B, int HW, int NG,
                                                       float eps, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int silu,
@@ -344,6 +364,84 @@ __global__ __launch_bounds__(1024) void gn_reg_kernel(const half_t* __restrict__
     }
 }
 
+template <int NP>
+__global__ __launch_bounds__(1024) void gn_reg_kernel(const half_t* __restrict__ x0, int C0, const half_t* __restrict__ x1, int C1, int B, int HW,
+                                                      int NG, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int silu, half_t* __restrict__ out) {
+    gn_reg_body<NP>(x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
+}
+template <int NP>
+__global__ __launch_bounds__(1024) void gn_reg_group_kernel(const GnArgsG g) {
+    const GnProb& p = g.p[blockIdx.y];
+    gn_reg_body<NP>(p.x0, g.C0, p.x1, g.C1, g.B, g.HW, g.NG, g.eps, p.gamma, p.beta, g.silu, p.out);
+}
+
+// one launch of a single-pass kernel, or (while the engine records) its record with the grouped form attached
+static unsigned long long gn_shape_hash(const GnRec& r, int kind) {
+    unsigned long long h = 1469598103934665603ull;
+    const int v[10] = {kind, r.C0, r.C1, r.B, r.HW, r.NG, r.silu, r.np_sel, (int)r.smem, 0};
+    for (int i = 0; i < 9; ++i) { h ^= (unsigned)v[i]; h *= 1099511628211ull; }
+    unsigned e; memcpy(&e, &r.eps, 4);
+    h ^= e; h *= 1099511628211ull;
+    return h;
+}
+static bool gn_same_shape(const GnRec& a, const GnRec& b) {
+    return a.C0 == b.C0 && a.C1 == b.C1 && a.B == b.B && a.HW == b.HW && a.NG == b.NG && a.silu == b.silu && a.eps == b.eps &&
+           a.np_sel == b.np_sel && a.smem == b.smem;
+}
+template <typename SingleFn, typename GroupFn>
+static int gn_group_dispatch(const void* const* args, int n, unsigned grid_x, hipStream_t s, unsigned block, SingleFn single, GroupFn group) {
+    const GnRec& r0 = *(const GnRec*)args[0];
+    if (n == 1) return single(r0, grid_x, s);
+    bool same = n <= FGDM_MAX_GROUP;
+    for (int k = 1; k < n && same; ++k) same = gn_same_shape(r0, *(const GnRec*)args[k]);
+    if (!same) {            // (a hash collision: cannot happen for two real layers, but then each problem simply runs alone)
+        for (int k = 0; k < n; ++k) { const int rc = single(*(const GnRec*)args[k], grid_x, s); if (rc != FGDM_OK) return rc; }
+        return FGDM_OK;
+    }
+    GnArgsG g{};
+    for (int k = 0; k < n; ++k) g.p[k] = ((const GnRec*)args[k])->p;
+    g.C0 = r0.C0; g.C1 = r0.C1; g.B = r0.B; g.HW = r0.HW; g.NG = r0.NG; g.silu = r0.silu; g.eps = r0.eps;
+    return group(g, r0, grid_x, (unsigned)n, s);
+}
+#define GN_SINGLE(KERNEL) [](const GnRec& r, unsigned gx, hipStream_t st) -> int {                                                       \
+        hipLaunchKernelGGL(KERNEL, dim3(gx), dim3(GN_BLOCK), r.smem, st, r.p.x0, r.C0, r.p.x1, r.C1, r.B, r.HW, r.NG, r.eps, r.p.gamma,   \
+                           r.p.beta, r.silu, r.p.out);                                                                                 \
+        return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP; }
+#define GN_GROUP(KERNEL) [](const GnArgsG& g, const GnRec& r, unsigned gx, unsigned n, hipStream_t st) -> int {                            \
+        hipLaunchKernelGGL(KERNEL, dim3(gx, n), dim3(GN_BLOCK), r.smem, st, g);                                                       \
+        return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP; }
+// np_sel: 6 / 11 / 16 / 21 = gn_reg_kernel<NP>; 256 / 512 = gn_fused_kernel<NT>
+static int gn_group_fn(const void* const* args, int n, unsigned grid_x, hipStream_t s) {
+    const int sel = ((const GnRec*)args[0])->np_sel;
+    switch (sel) {
+#define GN_BLOCK 1024
+        case 6: return gn_group_dispatch(args, n, grid_x, s, 1024, GN_SINGLE(gn_reg_kernel<6>), GN_GROUP(gn_reg_group_kernel<6>));
+        case 11: return gn_group_dispatch(args, n, grid_x, s, 1024, GN_SINGLE(gn_reg_kernel<11>), GN_GROUP(gn_reg_group_kernel<11>));
+        case 16: return gn_group_dispatch(args, n, grid_x, s, 1024, GN_SINGLE(gn_reg_kernel<16>), GN_GROUP(gn_reg_group_kernel<16>));
+        case 21: return gn_group_dispatch(args, n, grid_x, s, 1024, GN_SINGLE(gn_reg_kernel<21>), GN_GROUP(gn_reg_group_kernel<21>));
+#undef GN_BLOCK
+#define GN_BLOCK 256
+        case 256: return gn_group_dispatch(args, n, grid_x, s, 256, GN_SINGLE(gn_fused_kernel<256>), GN_GROUP(gn_fused_group_kernel<256>));
+#undef GN_BLOCK
+#define GN_BLOCK 512
+        case 512: return gn_group_dispatch(args, n, grid_x, s, 512, GN_SINGLE(gn_fused_kernel<512>), GN_GROUP(gn_fused_group_kernel<512>));
+#undef GN_BLOCK
+        default: return FGDM_ERR_ARG;
+    }
+}
+static thread_local bool g_gn_group = true;        // FGDM_GN_GROUP (read at fgdm_create, set by the engine per call): A/B knob, same bits either way
+void groupnorm_set_group(bool on) { g_gn_group = on; }
+// launch now, or record (with the grouped form attached when FGDM_GN_GROUP allows)
+static int gn_single_pass_launch(const GnRec& r, unsigned grid_x, hipStream_t s) {
+    const void* args[1] = {&r};
+    if (!fgdm_recording()) return gn_group_fn(args, 1, grid_x, s);
+    const GnRec rc = r;
+    fgdm_record_generic([rc, grid_x](hipStream_t rs) -> int { const void* a1[1] = {&rc}; return gn_group_fn(a1, 1, grid_x, rs); },
+                        (const void*)&gn_group_fn, g_gn_group ? gn_group_fn : nullptr, &r, sizeof(r), grid_x, gn_shape_hash(r, r.np_sel));
+    return FGDM_OK;
+}
+
 size_t groupnorm_ws_floats(int B, int HW) {
     const int nchunk = (HW + 63) / 64;   // upper bound for every chunk size >= 64
     return (size_t)B * nchunk * 64 + (size_t)B * 64;
@@ -381,12 +479,17 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
                     return FGDM_ERR_HIP;
                 attr_set = true;
             }
-            const dim3 grid((32 / NG) * 8 * ((B + 7) / 8)), block(1024);
-            if (np <= 6) FGDM_LAUNCH(gn_reg_kernel<6>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
-            else if (np <= 11) FGDM_LAUNCH(gn_reg_kernel<11>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
-            else if (np <= 16) FGDM_LAUNCH(gn_reg_kernel<16>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
-            else FGDM_LAUNCH(gn_reg_kernel<21>, grid, block, smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta, silu, out);
-            return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                if (hipFuncSetAttribute((const void*)gn_reg_group_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_reg_group_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_reg_group_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_reg_group_kernel<21>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                    return FGDM_ERR_HIP;
+                attr2_set = true;
+            }
+            GnRec r{{x0, x1, gamma, beta, out}, C0, C1, B, HW, NG, silu, eps, np <= 6 ? 6 : np <= 11 ? 11 : np <= 16 ? 16 : 21, (unsigned)smem};
+            return gn_single_pass_launch(r, (unsigned)((32 / NG) * 8 * ((B + 7) / 8)), s);
         }
         return 1;
     };
@@ -416,12 +519,15 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
                     return FGDM_ERR_HIP;
                 attr_set = true;
             }
-            const dim3 gridf((32 / NG) * 8 * ((B + 7) / 8));
-            if (NT == 512) FGDM_LAUNCH(gn_fused_kernel<512>, gridf, dim3(512), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma,
-                                              beta, silu, out);
-            else FGDM_LAUNCH(gn_fused_kernel<256>, gridf, dim3(256), smem, s, x0, C0, x1, C1, B, HW, NG, eps, gamma, beta,
-                                    silu, out);
-            return hipGetLastError() == hipSuccess ? FGDM_OK : FGDM_ERR_HIP;
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                if (hipFuncSetAttribute((const void*)gn_fused_group_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)gn_fused_group_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                    return FGDM_ERR_HIP;
+                attr2_set = true;
+            }
+            GnRec r{{x0, x1, gamma, beta, out}, C0, C1, B, HW, NG, silu, eps, NT, (unsigned)smem};
+            return gn_single_pass_launch(r, (unsigned)((32 / NG) * 8 * ((B + 7) / 8)), s);
         }
     }
     { const int rc = try_reg(); if (rc != 1) return rc; }

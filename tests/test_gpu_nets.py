@@ -394,7 +394,7 @@ def test_broadcast_layout_is_bit_identical_to_fp32_load():
 
 
 @pytest.mark.parametrize('knob,off,on,ncn', [('FGDM_PAIR_LAUNCH', '0', '1', 2), ('FGDM_PAIR_LAUNCH', '0', '1', 3), ('FGDM_PAIR_LAUNCH', '0', '1', 4),
-                                             ('FGDM_TWIN_STREAMS', '0', '1', 2), ('FGDM_GROUP_MAX', '2', '5', 3)])
+                                             ('FGDM_TWIN_STREAMS', '0', '1', 2), ('FGDM_GROUP_MAX', '2', '5', 3), ('FGDM_GN_GROUP', '0', '1', 3)])
 def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, off, on, ncn, monkeypatch):
     """The UNet encoder and the ControlNets are independent until the UNet's middle block (cldm.py:40,46).  Default: all walks are
     recorded and replayed in lockstep, twin GEMM launches of the UNet and ALL its ControlNets fused into grouped launches
@@ -438,6 +438,9 @@ def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, off, on
     if knob == 'FGDM_PAIR_LAUNCH':
         assert stats[0]['fused_launches'] == 0 and stats[1]['fused_launches'] > 50, stats
         assert stats[1]['fused_problems'] > 2 * stats[1]['fused_launches'], stats          # the UNet + all ControlNets in one launch
+    if knob == 'FGDM_GN_GROUP':        # the twins' single-pass GroupNorm launches join the grouped launches (same bodies, same bits)
+        assert stats[1]['fused_launches'] > stats[0]['fused_launches'] + 5, stats
+        assert stats[1]['fused_problems'] - stats[0]['fused_problems'] >= 3 * (stats[1]['fused_launches'] - stats[0]['fused_launches']), stats
     if knob == 'FGDM_GROUP_MAX':
         assert stats[0]['fused_launches'] > 0 and stats[0]['fused_problems'] == 2 * stats[0]['fused_launches'], stats
         assert stats[1]['fused_problems'] >= (1 + ncn) * 50 and stats[1]['fused_launches'] < stats[0]['fused_launches'], stats
