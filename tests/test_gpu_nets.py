@@ -393,7 +393,7 @@ def test_broadcast_layout_is_bit_identical_to_fp32_load():
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
-@pytest.mark.parametrize('knob,off,on,ncn', [('FGDM_PAIR_LAUNCH', '0', '1', 2), ('FGDM_PAIR_LAUNCH', '0', '1', 3), ('FGDM_PAIR_LAUNCH', '0', '1', 4),
+@pytest.mark.parametrize('knob,off,on,ncn', [('FGDM_PAIR_LAUNCH', '0', '1', 3), ('FGDM_PAIR_LAUNCH', '0', '1', 4),
                                              ('FGDM_TWIN_STREAMS', '0', '1', 2), ('FGDM_GROUP_MAX', '2', '5', 3), ('FGDM_GN_GROUP', '0', '1', 3)])
 def test_grouped_twin_launches_and_second_stream_are_bit_identical(knob, off, on, ncn, monkeypatch):
     """The UNet encoder and the ControlNets are independent until the UNet's middle block (cldm.py:40,46).  Default: all walks are
