@@ -461,7 +461,8 @@ int groupnorm_launch(const half_t* x0, int C0, const half_t* x1, int C1, int B, 
         static const int reg_hw = getenv("FGDM_GN_REG") ? atoi(getenv("FGDM_GN_REG")) : 1024;      // A/B knob: largest HW taken (0 = off)
         const bool reg_on = HW <= reg_hw;
         const int cpg = C >> 5;
-        for (int NG = 4; reg_on && NG >= 1; NG >>= 1) {           // the widest slice that fits: longer runs per pixel row
+        static const int ng_max = getenv("FGDM_GN_REG_NG") ? atoi(getenv("FGDM_GN_REG_NG")) : 4;        // experiment knob: widest slice, in groups
+        for (int NG = ng_max; reg_on && NG >= 1; NG >>= 1) {           // the widest slice that fits: longer runs per pixel row
             const int CW = NG * cpg;
             if (CW & 7) continue;
             const int OW = CW >> 3;
